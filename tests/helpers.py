@@ -1,0 +1,58 @@
+"""Shared test helpers (CPU side)."""
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+TINY = dict(embed_dims=16, series_embed_dims=8, num_chars=135,
+            durpred_conv_dims=16, durpred_rnn_dims=8, durpred_dropout=0.0,
+            pitch_conv_dims=16, pitch_rnn_dims=12, pitch_dropout=0.0, pitch_strength=1.0,
+            energy_conv_dims=16, energy_rnn_dims=8, energy_dropout=0.0, energy_strength=0.5,
+            rnn_dims=20, prenet_dims=16, prenet_k=4, postnet_num_highways=2,
+            prenet_dropout=0.0, postnet_dims=12, postnet_k=3, prenet_num_highways=2,
+            postnet_dropout=0.0, n_mels=10)
+
+# deliberately awkward sizes (nothing a multiple of 4) for edge coverage
+ODD = dict(embed_dims=10, series_embed_dims=6, num_chars=135,
+           durpred_conv_dims=7, durpred_rnn_dims=5, durpred_dropout=0.0,
+           pitch_conv_dims=9, pitch_rnn_dims=3, pitch_dropout=0.0, pitch_strength=0.7,
+           energy_conv_dims=6, energy_rnn_dims=5, energy_dropout=0.0, energy_strength=1.0,
+           rnn_dims=11, prenet_dims=10, prenet_k=5, postnet_num_highways=1,
+           prenet_dropout=0.0, postnet_dims=9, postnet_k=2, prenet_num_highways=3,
+           postnet_dropout=0.0, n_mels=7)
+
+FULL = dict(embed_dims=256, series_embed_dims=64, num_chars=135,
+            durpred_conv_dims=256, durpred_rnn_dims=64, durpred_dropout=0.5,
+            pitch_conv_dims=256, pitch_rnn_dims=128, pitch_dropout=0.5, pitch_strength=1.0,
+            energy_conv_dims=256, energy_rnn_dims=64, energy_dropout=0.5, energy_strength=1.0,
+            rnn_dims=512, prenet_dims=256, prenet_k=16, postnet_num_highways=4,
+            prenet_dropout=0.5, postnet_dims=256, postnet_k=8, prenet_num_highways=4,
+            postnet_dropout=0.0, n_mels=80)
+
+TRAIN_CFG = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss_factor=0.1,
+                 clip_grad_norm=1.0)
+
+
+def load_npz(name):
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def sub(d, prefix, as_torch=True):
+    out = {}
+    for k, v in d.items():
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = torch.from_numpy(np.array(v)) if as_torch else v
+    return out
+
+
+def maxdiff(a, b):
+    a = torch.as_tensor(a).detach().double()
+    b = torch.as_tensor(b).detach().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max())
