@@ -1,0 +1,222 @@
+// C-ABI glue, part 1: error handling, GEMM-shaped ops (linear / channels-last conv / conv bank) and
+// the LengthRegulator.  Declarations + reference citations live in include/fwdtaco_hip.h.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fwdtaco_hip.h"
+#include "ft_gemm.h"
+
+static thread_local char g_err[512] = "";
+
+void ft_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ft_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ft_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+    return FT_ERR_HIP;
+  }
+  return FT_OK;
+}
+
+int ft_lr_scan_impl(float*, int, int, int*, int*, hipStream_t);
+int ft_lr_expand_impl(const float*, const int*, float*, int*, int, int, int, int, hipStream_t);
+int ft_lr_bwd_impl(const float*, const int*, float*, int, int, int, int, hipStream_t);
+
+extern "C" {
+
+const char* ft_last_error(void) { return g_err; }
+int ft_abi_version(void) { return FWDTACO_ABI_VERSION; }
+
+int ft_device_info(int* cu_count, int* is_gfx950) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) {
+    ft_set_error("ft_device_info: no HIP device");
+    return FT_ERR_HIP;
+  }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (is_gfx950) *is_gfx950 = strncmp(p.gcnArchName, "gfx950", 6) == 0;
+  return FT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int ft_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int rows, int in_f,
+                  int out_f, int relu, int accumulate, void* stream) {
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  FtGemmTask& t = b.t[0];
+  t.A = x; t.B = w; t.C = y; t.bias = bias;
+  t.lda = ldx; t.ldb = in_f; t.ldc = ldy; t.b_tap_stride = 0;
+  t.M = rows; t.N = out_f; t.K = in_f; t.taps = 1;
+  t.amap = ft_rowmap_identity(rows);
+  t.relu = relu; t.accumulate = accumulate;
+  return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
+}
+
+int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
+                        float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
+                        void* stream) {
+  FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_multi_fwd: ntasks %d out of range", ntasks);
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < ntasks; ++i) {
+    FtGemmTask& t = b.t[i];
+    t.A = x; t.B = w[i]; t.C = y + col_offset[i]; t.bias = bias ? bias[i] : nullptr;
+    t.lda = ldx; t.ldb = in_f; t.ldc = ldy;
+    t.M = rows; t.N = out_f[i]; t.K = in_f; t.taps = 1;
+    t.amap = ft_rowmap_identity(rows);
+    t.relu = relu;
+  }
+  return ft_launch_gemm_rows(&b, ntasks, false, (hipStream_t)stream);
+}
+
+int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, long lddx, int rows, int in_f,
+                       int out_f, int accumulate, void* stream) {
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  FtGemmTask& t = b.t[0];
+  t.A = dy; t.B = w; t.C = dx;
+  t.lda = lddy; t.ldb = in_f; t.ldc = lddx;
+  t.M = rows; t.N = in_f; t.K = out_f; t.taps = 1;
+  t.amap = ft_rowmap_identity(rows);
+  t.accumulate = accumulate;
+  return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
+}
+
+static FtGemmTNTask linear_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int rows,
+                                   int in_f, int out_f, int B, int T, int x_shift, int accumulate) {
+  FtGemmTNTask t;
+  memset(&t, 0, sizeof(t));
+  t.A = dy; t.B = x; t.dst = dw;
+  t.lda = lddy; t.ldb = ldx;
+  t.ldm = in_f; t.ldn = 1; t.ldj = 0;
+  t.M = out_f; t.N = in_f; t.R = rows; t.taps = 1;
+  t.amap = ft_rowmap_identity(rows);
+  if (x_shift == 0) {
+    t.bmap = ft_rowmap_identity(rows);
+  } else {
+    FtRowMap m = {T, T, T, x_shift, 0};
+    t.bmap = m;
+  }
+  (void)B;
+  t.accumulate = accumulate;
+  return t;
+}
+
+size_t ft_linear_bwd_weight_workspace(int rows, int in_f, int out_f) {
+  FtGemmTNTask t = linear_bw_task(nullptr, out_f, nullptr, in_f, nullptr, rows, in_f, out_f, 1, rows, 0, 0);
+  return ft_gemm_tn_workspace_floats(t) * sizeof(float);
+}
+
+int ft_linear_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int rows, int in_f,
+                         int out_f, int B, int T, int x_shift, int accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(x_shift == 0 || (long)B * T == rows, "linear_bwd_weight: rows != B*T with a row shift");
+  FtGemmTNTask t = linear_bw_task(dy, lddy, x, ldx, dw, rows, in_f, out_f, B, T, x_shift, accumulate);
+  return ft_launch_gemm_tn(t, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// channels-last Conv1d
+static void conv_fwd_task(FtGemmTask& t, const float* x, long ldx, const float* wp, float* y, long ldy, int B,
+                          int T, int Cin, int Cout, int k, int Tout, int relu) {
+  memset(&t, 0, sizeof(t));
+  t.A = x; t.B = wp; t.C = y;
+  t.lda = ldx; t.ldb = Cin; t.ldc = ldy; t.b_tap_stride = (long)Cout * Cin;
+  t.M = B * Tout; t.N = Cout; t.K = Cin; t.taps = k;
+  FtRowMap m = {Tout, T, T, -(k / 2), 1};
+  t.amap = m;
+  t.relu = relu;
+}
+
+int ft_conv1d_fwd(const float* x, long ldx, const float* wp, const float* scale, const float* shift, float* y,
+                  long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, void* stream) {
+  FT_REQUIRE(k >= 1 && Tout >= 0 && Tout <= T + 1, "conv1d_fwd: bad k/Tout");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  conv_fwd_task(b.t[0], x, ldx, wp, y, ldy, B, T, Cin, Cout, k, Tout, relu);
+  b.t[0].scale = scale;
+  b.t[0].shift = shift;
+  return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
+}
+
+int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float* scale, const float* shift,
+                     float* ybank, int B, int T, int Cin, int C, int K, int Tout, int relu, void* stream) {
+  FT_REQUIRE(K >= 1 && K <= FT_MAX_TASKS, "conv_bank_fwd: K=%d unsupported (max %d)", K, FT_MAX_TASKS);
+  FT_REQUIRE(Tout == T || Tout == T + 1, "conv_bank_fwd: Tout must be T or T+1");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  long woff = 0;
+  for (int i = 0; i < K; ++i) {
+    int k = i + 1;
+    conv_fwd_task(b.t[i], x, ldx, wp_all + woff, ybank + (long)i * C, (long)K * C, B, T, Cin, C, k, Tout, relu);
+    b.t[i].scale = scale ? scale + (long)i * C : nullptr;
+    b.t[i].shift = shift ? shift + (long)i * C : nullptr;
+    woff += (long)k * C * Cin;
+  }
+  return ft_launch_gemm_rows(&b, K, false, (hipStream_t)stream);
+}
+
+int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
+                       int Cout, int k, int Tbuf, int Tvalid, int accumulate, void* stream) {
+  FT_REQUIRE(k >= 1 && Tvalid <= Tbuf, "conv1d_bwd_data: bad k/Tvalid");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  FtGemmTask& t = b.t[0];
+  t.A = dy; t.B = wp; t.C = dx;
+  t.lda = lddy; t.ldb = Cin; t.ldc = lddx; t.b_tap_stride = (long)Cout * Cin;
+  t.M = B * T; t.N = Cin; t.K = Cout; t.taps = k;
+  FtRowMap m = {T, Tbuf, Tvalid, k / 2, -1};     // dy row = t - tap + pad
+  t.amap = m;
+  t.accumulate = accumulate;
+  return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
+}
+
+static FtGemmTNTask conv_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T,
+                                 int Cin, int Cout, int k, int Tbuf, int Tvalid) {
+  FtGemmTNTask t;
+  memset(&t, 0, sizeof(t));
+  t.A = dy; t.B = x; t.dst = dw;
+  t.lda = lddy; t.ldb = ldx;
+  t.ldm = (long)Cin * k; t.ldn = k; t.ldj = 1;       // torch layout [Cout][Cin][k]
+  t.M = Cout; t.N = Cin; t.R = B * Tvalid; t.taps = k;
+  FtRowMap am = {Tvalid, Tbuf, Tvalid, 0, 0};
+  FtRowMap bm = {Tvalid, T, T, -(k / 2), 1};
+  t.amap = am;
+  t.bmap = bm;
+  return t;
+}
+
+size_t ft_conv1d_bwd_weight_workspace(int B, int T, int Cin, int Cout, int k, int Tvalid) {
+  FtGemmTNTask t = conv_bw_task(nullptr, Cout, nullptr, Cin, nullptr, B, T, Cin, Cout, k, Tvalid, Tvalid);
+  return ft_gemm_tn_workspace_floats(t) * sizeof(float);
+}
+
+int ft_conv1d_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T, int Cin,
+                         int Cout, int k, int Tbuf, int Tvalid, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  FT_REQUIRE(k >= 1 && Tvalid <= Tbuf, "conv1d_bwd_weight: bad k/Tvalid");
+  FtGemmTNTask t = conv_bw_task(dy, lddy, x, ldx, dw, B, T, Cin, Cout, k, Tbuf, Tvalid);
+  return ft_launch_gemm_tn(t, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+int ft_lr_scan(float* dur, int B, int Tx, int* cum, int* total, void* stream) {
+  return ft_lr_scan_impl(dur, B, Tx, cum, total, (hipStream_t)stream);
+}
+int ft_lr_expand(const float* x, const int* cum, float* y, int* src_idx, int B, int Tx, int Tm, int C,
+                 void* stream) {
+  return ft_lr_expand_impl(x, cum, y, src_idx, B, Tx, Tm, C, (hipStream_t)stream);
+}
+int ft_lr_bwd(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, void* stream) {
+  return ft_lr_bwd_impl(dy, cum, dx, B, Tx, Tm, C, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,39 @@
+// Common helpers for the forwardtacotron_amd HIP kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FT_OK 0
+#define FT_ERR_ARG 1
+#define FT_ERR_HIP 2
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void ft_set_error(const char* fmt, ...);
+int ft_check_launch(const char* what);
+
+#define FT_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ft_set_error(__VA_ARGS__);         \
+      return FT_ERR_ARG;                 \
+    }                                    \
+  } while (0)
+
+static inline int ft_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// accurate (ocml) forms: the recurrences run 841 dependent steps and must hold 1e-4 abs
+__device__ __forceinline__ float ft_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float ft_tanh(float x) { return tanhf(x); }
+
+__device__ __forceinline__ float ft_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double ft_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}

@@ -1,0 +1,391 @@
+// Exact-f32 MFMA GEMM family for gfx950 (v_mfma_f32_32x32x2_f32).
+//
+// All matmul-shaped work of the ForwardTacotron hot path funnels through two kernels:
+//   ft_gemm_rows_kernel : C[M,N] (+)= sum_tap shift_tap(A)[M,K] * B_tap    (linear, conv fwd,
+//                         conv bwd-data, RNN input projections)   -- NT or NN operand B
+//   ft_gemm_tn_kernel   : dW_tap[m][n] = sum_rows A[r][m] * shift_tap(B)[r][n]   (all weight grads)
+// "shift_tap" is the channels-last conv trick: a k-tap Conv1d over [B,T,C] is k GEMMs whose A rows
+// are the input rows shifted by (tap - pad) inside each batch item, zero outside [0,T).
+//
+// Tiling: 256 threads = 4 wave64 in 2x2, each wave TMxTN tiles of 32x32 (f32 accumulators in
+// AGPR/VGPR), BK = 32 per stage.  LDS tiles are K-major ([k][m]) so the MFMA operand fetch
+// (lane l: row l&31, k = kk + (l>>5)) is a conflict-free ds_read_b32 across 32 consecutive floats.
+// f32 MFMA runs at 64 cycles / instruction / SIMD, so operand staging (register prefetch of the next
+// K-stage while the current one is multiplied) is far from the bottleneck; the kernel is MFMA-bound.
+#include "ft_gemm.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+__device__ __forceinline__ float4 ld4(const float* p, int remaining, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (remaining >= 4 && vec) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (remaining > 0) v.x = p[0];
+    if (remaining > 1) v.y = p[1];
+    if (remaining > 2) v.z = p[2];
+    if (remaining > 3) v.w = p[3];
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int TM, int TN, bool BNC>
+__global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
+  const FtGemmTask& T = batch.t[blockIdx.z];
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int LDA = BM + 1;
+  constexpr int LDB = BNC ? BN + 4 : BN + 1;
+  constexpr int PA = BM / 32;                 // float4 per thread for A
+  constexpr int PB = BN / 32;                 // float4 per thread for B
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= T.M || n0 >= T.N) return;
+  const int tid = threadIdx.x;
+  const int kq = tid & 7, rr = tid >> 3;      // K-contiguous staging: 8 float4 along K, 32 rows / pass
+
+  // row map for this thread's A rows
+  int a_t[PA];
+  long a_base[PA];
+  bool a_ok[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    int m = m0 + rr + 32 * p;
+    a_ok[p] = m < T.M;
+    int b = m / T.amap.Tlog;
+    a_t[p] = m - b * T.amap.Tlog;
+    a_base[p] = (long)b * T.amap.Tstride;
+  }
+  const int kch = (T.K + BK - 1) / BK;
+  const int nch = T.taps * kch;
+
+  float4 ra[PA], rb[PB];
+  auto load_stage = [&](int c) {
+    const int j = c / kch;
+    const int k0 = (c - j * kch) * BK;
+    const int shift = T.amap.shift0 + j * T.amap.shift_step;
+    const int k = k0 + 4 * kq;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      int ts = a_t[p] + shift;
+      bool ok = a_ok[p] && ts >= 0 && ts < T.amap.Tvalid;
+      const float* ptr = T.A + (a_base[p] + ts) * T.lda + k;
+      ra[p] = ld4(ptr, ok ? T.K - k : 0, T.a_vec);
+    }
+    const float* Bj = T.B + (long)j * T.b_tap_stride;
+    if constexpr (!BNC) {
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        int n = n0 + rr + 32 * p;
+        rb[p] = ld4(Bj + (long)n * T.ldb + k, n < T.N ? T.K - k : 0, T.b_vec);
+      }
+    } else {
+      constexpr int NQ = BN / 4;              // float4 per k-row
+      constexpr int KR = 256 / NQ;            // k-rows per pass
+      const int nq = tid % NQ, kr = tid / NQ;
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        int kk = k0 + kr + KR * p;
+        int n = n0 + 4 * nq;
+        rb[p] = ld4(Bj + (long)kk * T.ldb + n, kk < T.K ? T.N - n : 0, T.b_vec);
+      }
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      int m = rr + 32 * p;
+      As[(4 * kq + 0) * LDA + m] = ra[p].x;
+      As[(4 * kq + 1) * LDA + m] = ra[p].y;
+      As[(4 * kq + 2) * LDA + m] = ra[p].z;
+      As[(4 * kq + 3) * LDA + m] = ra[p].w;
+    }
+    if constexpr (!BNC) {
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        int n = rr + 32 * p;
+        Bs[(4 * kq + 0) * LDB + n] = rb[p].x;
+        Bs[(4 * kq + 1) * LDB + n] = rb[p].y;
+        Bs[(4 * kq + 2) * LDB + n] = rb[p].z;
+        Bs[(4 * kq + 3) * LDB + n] = rb[p].w;
+      }
+    } else {
+      constexpr int NQ = BN / 4;
+      constexpr int KR = 256 / NQ;
+      const int nq = tid % NQ, kr = tid / NQ;
+#pragma unroll
+      for (int p = 0; p < PB; ++p)
+        *reinterpret_cast<float4*>(&Bs[(kr + KR * p) * LDB + 4 * nq]) = rb[p];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_stage(0);
+  for (int c = 0; c < nch; ++c) {
+    store_stage();
+    __syncthreads();
+    if (c + 1 < nch) load_stage(c + 1);
+    const float* ap = As + half * LDA + wm * 32 * TM + l31;
+    const float* bp = Bs + half * LDB + wn * 32 * TN + l31;
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = ap[2 * ks * LDA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bp[2 * ks * LDB + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds column l31, rows (e&3) + 8*(e>>2) + 4*half of each 32x32 tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + l31;
+      if (col >= T.N) continue;
+      const float bv = T.bias ? T.bias[col] : 0.f;
+      const float sc = T.scale ? T.scale[col] : 1.f;
+      const float sh = T.scale ? T.shift[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row >= T.M) continue;
+        float* cp = T.C + (long)row * T.ldc + col;
+        float v = acc[i][j][e] + bv;
+        if (T.accumulate) v += *cp;
+        if (T.relu) v = fmaxf(v, 0.f);
+        if (T.scale) v = v * sc + sh;
+        *cp = v;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: slab[z][m][n] = sum_{r in slice} A[map_a(r)][m] * B[map_b,tap(r)][n] ; z = tap*S + s
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* slab, int S, int rows_per_split) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int AQ = BM / 4, AR = 256 / AQ;   // float4 per k-row, k-rows per pass
+  constexpr int BQ = BN / 4, BR = 256 / BQ;
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int tap = blockIdx.z / S, s = blockIdx.z - tap * S;
+  const int r_begin = s * rows_per_split;
+  const int r_end = min(T.R, r_begin + rows_per_split);
+  const int tid = threadIdx.x;
+  const int aq = tid % AQ, ar = tid / AQ;
+  const int bq = tid % BQ, br = tid / BQ;
+  const int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
+  const int ashift = T.amap.shift0 + tap * T.amap.shift_step;
+
+  float4 ra[PA], rb[PB];
+  auto load_stage = [&](int r0) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      int r = r0 + ar + AR * p;
+      int b = r / T.amap.Tlog;
+      int ts = r - b * T.amap.Tlog + ashift;
+      bool ok = r < r_end && ts >= 0 && ts < T.amap.Tvalid;
+      int m = m0 + 4 * aq;
+      ra[p] = ld4(T.A + ((long)b * T.amap.Tstride + ts) * T.lda + m, ok ? T.M - m : 0, T.a_vec);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      int r = r0 + br + BR * p;
+      int b = r / T.bmap.Tlog;
+      int ts = r - b * T.bmap.Tlog + bshift;
+      bool ok = r < r_end && ts >= 0 && ts < T.bmap.Tvalid;
+      int n = n0 + 4 * bq;
+      rb[p] = ld4(T.B + ((long)b * T.bmap.Tstride + ts) * T.ldb + n, ok ? T.N - n : 0, T.b_vec);
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) *reinterpret_cast<float4*>(&As[(ar + AR * p) * LDA + 4 * aq]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<float4*>(&Bs[(br + BR * p) * LDB + 4 * bq]) = rb[p];
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (r_begin < r_end) {
+    load_stage(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+      store_stage();
+      __syncthreads();
+      if (r0 + BK < r_end) load_stage(r0 + BK);
+      const float* ap = As + half * LDA + wm * 32 * TM + l31;
+      const float* bp = Bs + half * LDB + wn * 32 * TN + l31;
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = ap[2 * ks * LDA + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = bp[2 * ks * LDB + 32 * j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  float* out = slab + (long)blockIdx.z * T.M * T.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + l31;
+      if (col >= T.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row < T.M) out[(long)row * T.N + col] = acc[i][j][e];
+      }
+    }
+}
+
+// dst[m*ldm + n*ldn + tap*ldj] (+)= sum_s slab[tap*S+s][m][n]   (fixed order -> bitwise reproducible)
+__global__ void ft_splitk_reduce_kernel(const float* slab, float* dst, int M, int N, int taps, int S,
+                                        long ldm, long ldn, long ldj, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)taps * M * N;
+  if (idx >= total) return;
+  int tap = (int)(idx / ((long)M * N));
+  long mn = idx - (long)tap * M * N;
+  int m = (int)(mn / N), n = (int)(mn - (long)m * N);
+  const float* p = slab + ((long)tap * S) * M * N + mn;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += p[(long)s * M * N];
+  float* d = dst + m * ldm + n * ldn + tap * ldj;
+  *d = accumulate ? *d + acc : acc;
+}
+
+struct TNPlan {
+  int tm, tn, S, rows_per_split;
+};
+
+TNPlan plan_tn(const FtGemmTNTask& t) {
+  TNPlan p;
+  bool small = ((long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128) * t.taps < 64) || t.M <= 64 || t.N <= 64;
+  p.tm = p.tn = small ? 1 : 2;
+  int bm = 64 * p.tm;
+  long tiles = (long)ft_cdiv(t.M, bm) * ft_cdiv(t.N, bm) * t.taps;
+  long want = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+  long maxs = (t.R + 4 * BK - 1) / (4 * BK);      // at least 128 rows per split
+  if (maxs < 1) maxs = 1;
+  long S = want < maxs ? want : maxs;
+  if (S > 65535 / (t.taps > 0 ? t.taps : 1)) S = 65535 / t.taps;
+  if (S < 1) S = 1;
+  long rps = (t.R + S - 1) / S;
+  rps = ((rps + BK - 1) / BK) * BK;
+  if (rps < BK) rps = BK;
+  S = (t.R + rps - 1) / rps;
+  if (S < 1) S = 1;
+  p.S = (int)S;
+  p.rows_per_split = (int)rps;
+  return p;
+}
+
+}  // namespace
+
+size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& t) {
+  TNPlan p = plan_tn(t);
+  return (size_t)p.S * t.taps * t.M * t.N;
+}
+
+int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream) {
+  FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "gemm_rows: bad task count %d", ntasks);
+  int maxM = 0, maxN = 0;
+  long tiles128 = 0;
+  for (int i = 0; i < ntasks; ++i) {
+    FtGemmTask& t = batch->t[i];
+    FT_REQUIRE(t.M >= 0 && t.N >= 0 && t.K >= 0 && t.taps >= 1, "gemm_rows: bad dims");
+    FT_REQUIRE(t.amap.Tlog > 0, "gemm_rows: bad row map");
+    t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0);
+    t.b_vec = (t.ldb % 4 == 0) && (t.b_tap_stride % 4 == 0) && (((uintptr_t)t.B) % 16 == 0);
+    if (t.M > maxM) maxM = t.M;
+    if (t.N > maxN) maxN = t.N;
+    tiles128 += (long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128);
+  }
+  if (maxM == 0 || maxN == 0) return FT_OK;
+  for (int i = ntasks; i < FT_MAX_TASKS; ++i) batch->t[i] = batch->t[0];
+  const bool big = tiles128 >= 192 && maxN > 64 && maxM > 64;
+  const int bm = big ? 128 : 64;
+  dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), ntasks);
+  FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_rows: grid too large");
+  if (big) {
+    if (b_ncontig)
+      hipLaunchKernelGGL((ft_gemm_rows_kernel<2, 2, true>), grid, dim3(256), 0, stream, *batch);
+    else
+      hipLaunchKernelGGL((ft_gemm_rows_kernel<2, 2, false>), grid, dim3(256), 0, stream, *batch);
+  } else {
+    if (b_ncontig)
+      hipLaunchKernelGGL((ft_gemm_rows_kernel<1, 1, true>), grid, dim3(256), 0, stream, *batch);
+    else
+      hipLaunchKernelGGL((ft_gemm_rows_kernel<1, 1, false>), grid, dim3(256), 0, stream, *batch);
+  }
+  return ft_check_launch("gemm_rows");
+}
+
+int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t workspace_floats,
+                      hipStream_t stream) {
+  FtGemmTNTask t = task_in;
+  FT_REQUIRE(t.M >= 0 && t.N >= 0 && t.R >= 0 && t.taps >= 1, "gemm_tn: bad dims");
+  if (t.M == 0 || t.N == 0) return FT_OK;
+  t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0);
+  t.b_vec = (t.ldb % 4 == 0) && (((uintptr_t)t.B) % 16 == 0);
+  TNPlan p = plan_tn(t);
+  size_t need = (size_t)p.S * t.taps * t.M * t.N;
+  FT_REQUIRE(workspace && workspace_floats >= need, "gemm_tn: workspace too small (%zu < %zu floats)",
+             workspace_floats, need);
+  const int bm = 64 * p.tm;
+  dim3 grid(ft_cdiv(t.M, bm), ft_cdiv(t.N, bm), p.S * t.taps);
+  FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_tn: grid too large");
+  if (p.tm == 2)
+    hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
+  else
+    hipLaunchKernelGGL((ft_gemm_tn_kernel<1, 1>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
+  int rc = ft_check_launch("gemm_tn");
+  if (rc) return rc;
+  long total = (long)t.taps * t.M * t.N;
+  hipLaunchKernelGGL(ft_splitk_reduce_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, stream, workspace, t.dst,
+                     t.M, t.N, t.taps, p.S, t.ldm, t.ldn, t.ldj, t.accumulate);
+  return ft_check_launch("splitk_reduce");
+}

@@ -1,0 +1,174 @@
+"""GPU parity: GEMM-shaped ops + LengthRegulator through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def H():
+    from forwardtacotron_amd import hip
+    assert torch.cuda.is_available()
+    return hip
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('rows,in_f,out_f', [(7, 5, 3), (64, 32, 64), (130, 257, 66), (4096, 256, 512),
+                                             (1, 1, 1), (300, 1024, 80), (333, 10, 7)])
+def test_linear_fwd_bwd(H, rows, in_f, out_f):
+    g = torch.Generator().manual_seed(rows + in_f)
+    x = torch.randn(rows, in_f, generator=g); w = torch.randn(out_f, in_f, generator=g)
+    b = torch.randn(out_f, generator=g); dy = torch.randn(rows, out_f, generator=g)
+    y = H.linear_fwd(dev(x), dev(w), dev(b))
+    ref = x.double() @ w.double().t() + b.double()
+    assert rel_err(y, ref) < 2e-6
+    yr = H.linear_fwd(dev(x), dev(w), dev(b), relu=True)
+    assert rel_err(yr, ref.clamp_min(0)) < 2e-6
+    dx = H.linear_bwd_data(dev(dy), dev(w))
+    assert rel_err(dx, dy.double() @ w.double()) < 2e-6
+    dw = H.linear_bwd_weight(dev(dy), dev(x))
+    assert rel_err(dw, dy.double().t() @ x.double()) < 2e-6
+
+
+def test_linear_multi(H):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 50, 24, generator=g)
+    ws = [torch.randn(n, 24, generator=g) for n in (24, 24, 9)]
+    bs = [torch.randn(24, generator=g), None, torch.randn(9, generator=g)]
+    y = H.linear_multi_fwd(dev(x), [dev(w) for w in ws], [dev(b) if b is not None else None for b in bs])
+    ref = torch.cat([x @ w.t() + (b if b is not None else 0) for w, b in zip(ws, bs)], dim=-1)
+    assert rel_err(y, ref) < 2e-6
+
+
+def test_linear_bwd_weight_shift(H):
+    from forwardtacotron_amd.hip import linear_bwd_weight_raw
+    g = torch.Generator().manual_seed(4)
+    B, T, I, O = 3, 11, 6, 9
+    dy = torch.randn(B, T, O, generator=g); x = torch.randn(B, T, I, generator=g)
+    for shift in (-1, 1):
+        xs = torch.zeros_like(x)
+        if shift == -1:
+            xs[:, 1:] = x[:, :-1]
+        else:
+            xs[:, :-1] = x[:, 1:]
+        ref = dy.reshape(-1, O).double().t() @ xs.reshape(-1, I).double()
+        dyd, xd = dev(dy), dev(x)
+        dw = torch.empty(O, I, device='cuda')
+        linear_bwd_weight_raw(dyd.data_ptr(), O, xd.data_ptr(), I, dw, B * T, I, O, B=B, T=T, x_shift=shift)
+        assert rel_err(dw, ref) < 2e-6
+
+
+def _conv_ref(x_cl, w, relu):
+    from oracle import ft_oracle as O
+    y = O.conv1d(x_cl.transpose(1, 2).double(), w.double())
+    if relu:
+        y = y.clamp_min(0)
+    return y.transpose(1, 2)     # [B,Tout_full,Cout]
+
+
+@pytest.mark.parametrize('B,T,Cin,Cout,k', [(2, 9, 6, 8, 5), (3, 11, 5, 7, 4), (2, 17, 16, 16, 1), (1, 5, 3, 4, 2),
+                                            (2, 40, 33, 70, 16), (4, 128, 64, 256, 5), (3, 7, 10, 9, 3),
+                                            (2, 3, 4, 4, 7)])
+def test_conv1d_fwd_bwd(H, B, T, Cin, Cout, k):
+    g = torch.Generator().manual_seed(B * 100 + k)
+    x = torch.randn(B, T, Cin, generator=g); w = torch.randn(Cout, Cin, k, generator=g)
+    wp = H.conv_pack_weight(dev(w))
+    assert maxdiff(wp.cpu(), w.permute(2, 0, 1).contiguous()) == 0.0
+    full = _conv_ref(x, w, True)
+    Tfull = full.shape[1]
+    for Tout in sorted({T, Tfull}):
+        y = H.conv1d_fwd(dev(x), wp, relu=True, Tout=Tout)
+        assert rel_err(y, full[:, :Tout]) < 3e-6, (Tout,)
+    sc = torch.rand(Cout, generator=g) + 0.5; sh = torch.randn(Cout, generator=g)
+    y = H.conv1d_fwd(dev(x), wp, relu=True, Tout=T, scale=dev(sc), shift=dev(sh))
+    assert rel_err(y, full[:, :T] * sc.double() + sh.double()) < 3e-6
+    # backward vs autograd of the oracle conv (no relu), using all Tfull rows as valid
+    xg = x.double().transpose(1, 2).clone().requires_grad_(True)
+    wg = w.double().clone().requires_grad_(True)
+    from oracle import ft_oracle as O
+    yo = O.conv1d(xg, wg)
+    dy = torch.randn(B, Tfull, Cout, generator=g)
+    (yo * dy.double().transpose(1, 2)).sum().backward()
+    dyd = dev(dy)
+    dx = torch.empty(B, T, Cin, device='cuda')
+    H.conv1d_bwd_data_raw(dyd.data_ptr(), Cout, wp, dx, B, T, Tfull, Tfull, False)
+    assert rel_err(dx, xg.grad.transpose(1, 2)) < 3e-6
+    dw = torch.empty(Cout, Cin, k, device='cuda')
+    H.conv1d_bwd_weight_raw(dyd.data_ptr(), Cout, dev(x), dw, Tfull, Tfull)
+    assert rel_err(dw, wg.grad) < 3e-6
+    if Tfull == T + 1:
+        # only the first T rows valid (sliced even-k conv)
+        xg.grad = None; wg.grad = None
+        yo = O.conv1d(xg, wg)[:, :, :T]
+        (yo * dy[:, :T].double().transpose(1, 2)).sum().backward()
+        H.conv1d_bwd_data_raw(dyd.data_ptr(), Cout, wp, dx, B, T, Tfull, T, False)
+        assert rel_err(dx, xg.grad.transpose(1, 2)) < 3e-6
+        H.conv1d_bwd_weight_raw(dyd.data_ptr(), Cout, dev(x), dw, Tfull, T)
+        assert rel_err(dw, wg.grad) < 3e-6
+
+
+@pytest.mark.parametrize('B,T,Cin,C,K', [(2, 9, 6, 8, 4), (3, 20, 10, 9, 5), (2, 64, 80, 64, 8), (1, 33, 32, 32, 16)])
+def test_conv_bank_fwd(H, B, T, Cin, C, K):
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(B, T, Cin, generator=g)
+    ws = [torch.randn(C, Cin, k, generator=g) for k in range(1, K + 1)]
+    wp_all = torch.cat([H.conv_pack_weight(dev(w)).reshape(-1) for w in ws])
+    y = H.conv_bank_fwd(dev(x), wp_all, K, C, relu=True, Tout=T + 1)
+    for i, w in enumerate(ws):
+        full = _conv_ref(x, w, True)
+        n = full.shape[1]
+        assert rel_err(y[:, :n, i * C:(i + 1) * C], full) < 3e-6, i
+
+
+def test_length_regulator_golden(H):
+    L = load_npz('layers.npz')
+    x = torch.from_numpy(L['lr/x']); dur = torch.from_numpy(L['lr/dur_in'].copy())
+    durd = dev(dur)
+    cum, total = H.lr_scan(durd)
+    assert np.array_equal(durd.cpu().numpy(), L['lr/dur_after'])
+    Tm = int(total.max())
+    y = H.lr_expand(dev(x), cum, Tm)
+    assert np.array_equal(y.cpu().numpy(), L['lr/y'])      # bit-exact
+
+
+@pytest.mark.parametrize('B,Tx,C,maxd', [(3, 7, 5, 4), (32, 128, 512, 12), (5, 200, 16, 3), (2, 65, 4, 40), (1, 1, 1, 2)])
+def test_length_regulator_vs_oracle(H, B, Tx, C, maxd):
+    from oracle import ft_oracle as O
+    g = torch.Generator().manual_seed(B + Tx)
+    x = torch.randn(B, Tx, C, generator=g)
+    dur = torch.randint(-1, maxd, (B, Tx), generator=g).float() + torch.rand(B, Tx, generator=g) * 0.99
+    xo = x.clone().requires_grad_(True)
+    duro = dur.clone()
+    yo = O.length_regulate(xo, duro)
+    durd = dev(dur)
+    cum, total = H.lr_scan(durd)
+    assert np.array_equal(durd.cpu().numpy(), duro.numpy())
+    src_o, tot_o = O.lr_index_map(duro.numpy())
+    assert np.array_equal(total.cpu().numpy(), tot_o.astype(np.int32))
+    Tm = int(total.max())
+    y, src = H.lr_expand(dev(x), cum, Tm, want_src=True)
+    assert np.array_equal(y.cpu().numpy(), yo.detach().numpy())
+    assert np.array_equal(src.cpu().numpy(), src_o.astype(np.int32))
+    dy = torch.randn(B, Tm, C, generator=g)
+    (yo * dy).sum().backward()
+    dx = H.lr_bwd(dev(dy), cum, Tx)
+    assert maxdiff(dx.cpu(), xo.grad) < 1e-5
+
+
+def test_length_regulator_all_zero(H):
+    durd = torch.zeros(2, 3, device='cuda')
+    cum, total = H.lr_scan(durd)
+    assert int(total.max()) == 0
+    y = H.lr_expand(torch.randn(2, 3, 4, device='cuda'), cum, 0)
+    assert tuple(y.shape) == (2, 0, 4)
