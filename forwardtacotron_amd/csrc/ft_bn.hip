@@ -1,0 +1,271 @@
+// BatchNorm1d over channels-last activations (models/common_layers.py:51,57) + column reductions.
+//
+// Training statistics follow torch.nn.BatchNorm1d exactly: mean / biased variance over ALL B*T positions
+// (padding included), running stats updated with momentum and the UNBIASED variance, counter += 1.
+// CBHG quirk (common_layers.py:97-99): an even-k bank conv yields T+1 outputs and its BatchNorm sees all
+// of them before the caller slices [:T].  The bank buffer is therefore [B, T+1, K*C] and the number of
+// valid rows depends on the channel group: tvalid(c) = Tbuf-1 for odd k, Tbuf for even k (group > 0).
+//
+// All reductions are two-stage (per-block double partials -> ordered finalize), so results are bitwise
+// reproducible run to run.  These kernels are HBM-bound: one pass over the activation per stage.
+#include "ft_common.h"
+
+namespace {
+
+__device__ __forceinline__ int tvalid_of(int c, int Tbuf, int group) {
+  return (group > 0 && (((c / group) + 1) & 1)) ? Tbuf - 1 : Tbuf;
+}
+
+// mode 0: (sum y, sum y^2) over rows t < tvalid(c) of y[B,Tbuf,C]
+// mode 1: (sum dout, sum dout*xhat), dout[B,Tout,C] (zero for t >= Tout), xhat from y, mean, rstd
+// mode 2: (sum x, 0) over all rows of x[rows, ldx] (bias gradients); Tbuf = rows, B = 1
+template <int MODE>
+__global__ __launch_bounds__(256) void ft_col_partial_kernel(const float* __restrict__ y, long ldy,
+                                                             const float* __restrict__ dout,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, int B, int Tbuf, int Tout,
+                                                             int C, int group, int rows_per_chunk,
+                                                             double* __restrict__ partial) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long rows = (long)B * Tbuf;
+  long r0 = (long)blockIdx.y * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    const int tv = tvalid_of(c, Tbuf, group);
+    float mu = 0.f, rs = 0.f;
+    if (MODE == 1) {
+      mu = mean[c];
+      rs = rstd[c];
+    }
+    long r = r0 + rl;
+    int b = (int)(r / Tbuf);
+    int t = (int)(r - (long)b * Tbuf);
+    for (; r < r1; r += 4) {
+      if (t < tv) {
+        float v = y[r * ldy + c];
+        if (MODE == 0) {
+          s0 += (double)v;
+          s1 += (double)v * (double)v;
+        } else if (MODE == 1) {
+          if (t < Tout) {
+            float g = dout[((long)b * Tout + t) * C + c];
+            s0 += (double)g;
+            s1 += (double)g * (double)((v - mu) * rs);
+          }
+        } else {
+          s0 += (double)v;
+        }
+      }
+      t += 4;
+      while (t >= Tbuf) {
+        t -= Tbuf;
+        ++b;
+      }
+    }
+  }
+  red[0][rl][cl] = s0;
+  red[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double a0 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    double a1 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    partial[((long)blockIdx.y * C + c) * 2 + 0] = a0;
+    partial[((long)blockIdx.y * C + c) * 2 + 1] = a1;
+  }
+}
+
+__global__ void ft_bn_finalize_kernel(const double* __restrict__ partial, int nchunks, int B, int Tbuf, int C, int group,
+                                      float momentum, float eps, float* __restrict__ running_mean,
+                                      float* __restrict__ running_var, long* __restrict__ nbt,
+                                      float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < nchunks; ++i) {
+    s0 += partial[((long)i * C + c) * 2 + 0];
+    s1 += partial[((long)i * C + c) * 2 + 1];
+  }
+  double n = (double)B * (double)tvalid_of(c, Tbuf, group);
+  double mu = s0 / n;
+  double var = s1 / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mu;
+  save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+  }
+}
+
+// finalize of modes 1 / 2: out0[c] = sum0, out1[c] = sum1 (floats)
+__global__ void ft_col_finalize_kernel(const double* __restrict__ partial, int nchunks, int C, float* __restrict__ out0,
+                                       float* __restrict__ out1, float scale0, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < nchunks; ++i) {
+    s0 += partial[((long)i * C + c) * 2 + 0];
+    s1 += partial[((long)i * C + c) * 2 + 1];
+  }
+  if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)(s0 * scale0);
+  if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)s1;
+}
+
+// out[b,t,c] = (y[b,t,c]-mean)*rstd*gamma + beta (+ residual[b,t,c])   for t < Tout
+__global__ __launch_bounds__(256) void ft_bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ residual, float* __restrict__ out,
+                                                          int B, int Tbuf, int Tout, int C) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * Tout * C;
+  if (idx >= total) return;
+  int c = (int)(idx % C);
+  long row = idx / C;
+  int b = (int)(row / Tout), t = (int)(row - (long)b * Tout);
+  float v = y[((long)b * Tbuf + t) * C + c];
+  float o = (v - mean[c]) * rstd[c] * gamma[c] + beta[c];
+  if (residual) o += residual[idx];
+  out[idx] = o;
+}
+
+// dy[b,t,c] = gamma*rstd*(dout - dbeta/n - xhat*dgamma/n) [* (y>0)]  for t < tvalid(c), else 0
+__global__ __launch_bounds__(256) void ft_bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ dgamma,
+                                                              const float* __restrict__ dbeta, float* __restrict__ dy,
+                                                              int B, int Tbuf, int Tout, int C, int group, int relu) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * Tbuf * C;
+  if (idx >= total) return;
+  int c = (int)(idx % C);
+  long row = idx / C;
+  int b = (int)(row / Tbuf), t = (int)(row - (long)b * Tbuf);
+  int tv = tvalid_of(c, Tbuf, group);
+  float r = 0.f;
+  if (t < tv) {
+    float v = y[idx];
+    float g = t < Tout ? dout[((long)b * Tout + t) * C + c] : 0.f;
+    float inv_n = 1.0f / ((float)B * (float)tv);
+    float xh = (v - mean[c]) * rstd[c];
+    r = gamma[c] * rstd[c] * (g - dbeta[c] * inv_n - xh * dgamma[c] * inv_n);
+    if (relu && !(v > 0.f)) r = 0.f;
+  }
+  dy[idx] = r;
+}
+
+// eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
+__global__ void ft_bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                  float* scale, float* shift, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = s;
+  shift[c] = beta[c] - rm[c] * s;
+}
+
+struct ChunkPlan {
+  int nchunks, rows_per_chunk;
+};
+ChunkPlan plan_chunks(long rows, int C) {
+  int cb = ft_cdiv(C, 64);
+  long want = 2048 / (cb > 0 ? cb : 1);
+  if (want < 1) want = 1;
+  long maxc = (rows + 63) / 64;
+  if (maxc < 1) maxc = 1;
+  long n = want < maxc ? want : maxc;
+  if (n > 65535) n = 65535;
+  long rpc = (rows + n - 1) / n;
+  rpc = ((rpc + 3) / 4) * 4;
+  if (rpc < 4) rpc = 4;
+  n = (rows + rpc - 1) / rpc;
+  if (n < 1) n = 1;
+  ChunkPlan p = {(int)n, (int)rpc};
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ft_bn_workspace(int B, int Tbuf, int C) {
+  ChunkPlan p = plan_chunks((long)B * Tbuf, C);
+  return (size_t)p.nchunks * C * 2 * sizeof(double);
+}
+
+int ft_bn_train_fwd(const float* y, const float* gamma, const float* beta, const float* residual, float* out,
+                    float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
+                    float* save_rstd, int B, int Tbuf, int Tout, int C, int group, float momentum, float eps,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(B > 0 && Tbuf > 0 && C > 0 && Tout <= Tbuf, "bn_train_fwd: bad dims");
+  FT_REQUIRE(workspace && workspace_bytes >= ft_bn_workspace(B, Tbuf, C), "bn_train_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ChunkPlan p = plan_chunks((long)B * Tbuf, C);
+  hipLaunchKernelGGL(ft_col_partial_kernel<0>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, nullptr,
+                     nullptr, nullptr, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
+  hipLaunchKernelGGL(ft_bn_finalize_kernel, dim3(ft_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace,
+                     p.nchunks, B, Tbuf, C, group, momentum, eps, running_mean, running_var, num_batches_tracked,
+                     save_mean, save_rstd);
+  if (out && Tout > 0) {
+    long total = (long)B * Tout * C;
+    hipLaunchKernelGGL(ft_bn_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, y, save_mean, save_rstd, gamma,
+                       beta, residual, out, B, Tbuf, Tout, C);
+  }
+  return ft_check_launch("bn_train_fwd");
+}
+
+int ft_bn_bwd(const float* dout, const float* y, const float* gamma, const float* save_mean, const float* save_rstd,
+              float* dy, float* dgamma, float* dbeta, int B, int Tbuf, int Tout, int C, int group, int relu,
+              void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(B > 0 && Tbuf > 0 && C > 0 && Tout <= Tbuf, "bn_bwd: bad dims");
+  FT_REQUIRE(workspace && workspace_bytes >= ft_bn_workspace(B, Tbuf, C), "bn_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ChunkPlan p = plan_chunks((long)B * Tbuf, C);
+  hipLaunchKernelGGL(ft_col_partial_kernel<1>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, dout,
+                     save_mean, save_rstd, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
+  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace,
+                     p.nchunks, C, dbeta, dgamma, 1.0f, 0);
+  long total = (long)B * Tbuf * C;
+  hipLaunchKernelGGL(ft_bn_bwd_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, dout, y, save_mean, save_rstd,
+                     gamma, dgamma, dbeta, dy, B, Tbuf, Tout, C, group, relu);
+  return ft_check_launch("bn_bwd");
+}
+
+int ft_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                    float eps, float* scale, float* shift, int C, void* stream) {
+  if (C <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_bn_fold_kernel, dim3(ft_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, scale, shift, C);
+  return ft_check_launch("bn_fold_eval");
+}
+
+size_t ft_colsum_workspace(int rows, int C) { return ft_bn_workspace(1, rows > 0 ? rows : 1, C > 0 ? C : 1); }
+
+int ft_colsum(const float* x, long ldx, float* out, int rows, int C, float scale, int accumulate, void* workspace,
+              size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(rows >= 0 && C >= 0, "colsum: bad dims");
+  if (C == 0) return FT_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (rows == 0) {
+    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * C, s);
+    return FT_OK;
+  }
+  FT_REQUIRE(workspace && workspace_bytes >= ft_colsum_workspace(rows, C), "colsum: workspace too small");
+  ChunkPlan p = plan_chunks(rows, C);
+  hipLaunchKernelGGL(ft_col_partial_kernel<2>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, x, ldx, nullptr,
+                     nullptr, nullptr, 1, rows, rows, C, 0, p.rows_per_chunk, (double*)workspace);
+  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace,
+                     p.nchunks, C, out, nullptr, scale, accumulate);
+  return ft_check_launch("colsum");
+}
+
+}  // extern "C"

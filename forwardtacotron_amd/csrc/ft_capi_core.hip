@@ -137,13 +137,15 @@ static void conv_fwd_task(FtGemmTask& t, const float* x, long ldx, const float* 
 }
 
 int ft_conv1d_fwd(const float* x, long ldx, const float* wp, const float* scale, const float* shift, float* y,
-                  long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, void* stream) {
+                  long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, int accumulate,
+                  void* stream) {
   FT_REQUIRE(k >= 1 && Tout >= 0 && Tout <= T + 1, "conv1d_fwd: bad k/Tout");
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   conv_fwd_task(b.t[0], x, ldx, wp, y, ldy, B, T, Cin, Cout, k, Tout, relu);
   b.t[0].scale = scale;
   b.t[0].shift = shift;
+  b.t[0].accumulate = accumulate;
   return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
 }
 

@@ -1,5 +1,5 @@
 // Element-wise / data-movement kernels (HBM-bound): conv weight packing, embedding, highway gates,
-// maxpool, residual, conditioning projections, layout changes.  See include/fwdtaco_hip.h.
+// maxpool, conditioning projections, layout changes, masked L1.  See include/fwdtaco_hip.h.
 #include "ft_common.h"
 
 namespace {
@@ -14,6 +14,242 @@ __global__ void ft_pack_conv_w_kernel(const float* __restrict__ w, float* __rest
   wp[idx] = w[rem * k + j];
 }
 
+// ---- dropout (F.dropout, forward_tacotron.py:35 ; common_layers.py:106,110) -------------------------
+// Counter-based mask: keep(i) = hash(seed, i) >= p ; the backward re-derives the same mask from the seed,
+// so no mask tensor is stored.  out = keep ? x/(1-p) : 0
+__device__ __forceinline__ uint32_t ft_hash32(uint64_t v) {
+  v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
+  return (uint32_t)v;
+}
+__global__ void ft_dropout_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float p,
+                                  uint64_t seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h = ft_hash32(seed * 0x9e3779b97f4a7c15ULL + (uint64_t)i);
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  out[i] = u >= p ? x[i] / (1.0f - p) : 0.f;
+}
+__global__ void ft_scale_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float s) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i] * s;
+}
+
+// ---- embedding ------------------------------------------------------------------------------------
+__global__ void ft_embedding_fwd_kernel(const long* __restrict__ idx, const float* __restrict__ w,
+                                        float* __restrict__ out, long rows, int C, int V, int* __restrict__ err) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  long r = i / C;
+  int c = (int)(i - r * C);
+  long v = idx[r];
+  if (v < 0 || v >= V) {
+    if (c == 0) atomicExch(err, 1);
+    out[i] = 0.f;
+    return;
+  }
+  out[i] = w[v * C + c];
+}
+
+// dW[v][c] = sum over rows with idx==v of dout[row][c]  (row order -> reproducible)
+__global__ __launch_bounds__(256) void ft_embedding_bwd_kernel(const long* __restrict__ idx,
+                                                               const float* __restrict__ dout,
+                                                               float* __restrict__ dw, long rows, int C) {
+  __shared__ float red[4][64];
+  const int v = blockIdx.x;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  float acc = 0.f;
+  for (long r = rl; r < rows; r += 4)
+    if (idx[r] == v && c < C) acc += dout[r * C + c];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) dw[(long)v * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+// ---- highway (common_layers.py:35-40): x12 = [W1 x + b1 | W2 x + b2] -------------------------------
+__global__ void ft_highway_fwd_kernel(const float* __restrict__ x12, const float* __restrict__ x,
+                                      float* __restrict__ out, long rows, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  long r = i / C;
+  int c = (int)(i - r * C);
+  float x1 = x12[r * 2 * C + c], x2 = x12[r * 2 * C + C + c];
+  float g = ft_sigmoid(x2);
+  out[i] = g * fmaxf(x1, 0.f) + (1.f - g) * x[i];
+}
+
+// d12 = [dout*g*(x1>0) | dout*(relu(x1)-x)*g*(1-g)] ; dx_direct = dout*(1-g)
+__global__ void ft_highway_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x12,
+                                      const float* __restrict__ x, float* __restrict__ d12,
+                                      float* __restrict__ dx, long rows, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  long r = i / C;
+  int c = (int)(i - r * C);
+  float x1 = x12[r * 2 * C + c], x2 = x12[r * 2 * C + C + c];
+  float g = ft_sigmoid(x2);
+  float d = dout[i];
+  float rx1 = fmaxf(x1, 0.f);
+  d12[r * 2 * C + c] = x1 > 0.f ? d * g : 0.f;
+  d12[r * 2 * C + C + c] = d * (rx1 - x[i]) * g * (1.f - g);
+  dx[i] = d * (1.f - g);
+}
+
+// ---- MaxPool1d(2,1,1)[:T] over channels-last: out[t] = max(x[t-1], x[t]) (first max wins ties) -----
+__global__ void ft_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * T * C;
+  if (i >= total) return;
+  long row = i / C;
+  int t = (int)(row % T);
+  float v = x[i];
+  if (t > 0) {
+    float p = x[i - C];
+    v = v > p ? v : p;
+  }
+  out[i] = v;
+}
+// torch's max_pool backward sends the gradient to the FIRST maximal element of the window (t-1 on ties)
+__global__ void ft_maxpool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                      float* __restrict__ dx, int B, int T, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * T * C;
+  if (i >= total) return;
+  long row = i / C;
+  int t = (int)(row % T);
+  float v = x[i];
+  float g = 0.f;
+  if (t == 0 || v > x[i - C]) g += dout[i];            // window t picks x[t]
+  if (t + 1 < T && !(x[i + C] > v)) g += dout[i + C];  // window t+1 picks x[t] (its first element)
+  dx[i] = g;
+}
+
+// ---- pitch / energy conditioning (forward_tacotron.py:137-143) -------------------------------------
+// out[b,t,c] = x[b,t,c] + sp*(bp[c] + sum_j wp[c][j]*pitch[b,t+j-1]) + se*(be[c] + sum_j we[c][j]*energy[b,t+j-1])
+__global__ void ft_cond_add_kernel(const float* __restrict__ x, const float* __restrict__ pitch,
+                                   const float* __restrict__ energy, const float* __restrict__ wp,
+                                   const float* __restrict__ bp, const float* __restrict__ we,
+                                   const float* __restrict__ be, float sp, float se, float* __restrict__ out, int B,
+                                   int T, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * T * C;
+  if (i >= total) return;
+  int c = (int)(i % C);
+  long row = i / C;
+  int t = (int)(row % T);
+  const float* p = pitch + row;
+  const float* e = energy + row;
+  float pm = t > 0 ? p[-1] : 0.f, pc = p[0], pn = t + 1 < T ? p[1] : 0.f;
+  float em = t > 0 ? e[-1] : 0.f, ec = e[0], en = t + 1 < T ? e[1] : 0.f;
+  float a = bp[c] + wp[c * 3 + 0] * pm + wp[c * 3 + 1] * pc + wp[c * 3 + 2] * pn;
+  float b = be[c] + we[c * 3 + 0] * em + we[c * 3 + 1] * ec + we[c * 3 + 2] * en;
+  out[i] = x[i] + sp * a + se * b;
+}
+// P[row][0..7] = [p[t-1], p[t], p[t+1], 1, e[t-1], e[t], e[t+1], 1]  (weight grads = dy^T P via the TN GEMM)
+__global__ void ft_cond_taps_kernel(const float* __restrict__ pitch, const float* __restrict__ energy,
+                                    float* __restrict__ P, int B, int T) {
+  long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= (long)B * T) return;
+  int t = (int)(row % T);
+  const float* p = pitch + row;
+  const float* e = energy + row;
+  float* o = P + row * 8;
+  o[0] = t > 0 ? p[-1] : 0.f; o[1] = p[0]; o[2] = t + 1 < T ? p[1] : 0.f; o[3] = 1.f;
+  o[4] = t > 0 ? e[-1] : 0.f; o[5] = e[0]; o[6] = t + 1 < T ? e[1] : 0.f; o[7] = 1.f;
+}
+
+// ---- [B,T,C] <-> [B,C,Tout] with padding (forward_tacotron.py:155,159,236-239) ---------------------
+// out[b,c,t] = t < T ? x[b,t,c] : pad   for t < Tout
+__global__ __launch_bounds__(256) void ft_transpose_pad_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                               int T, int C, int Tout, float pad) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    int t = t0 + i, c = c0 + tx;
+    tile[i][tx] = (t < T && c < C) ? x[((long)b * T + t) * C + c] : pad;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, t = t0 + tx;
+    if (c < C && t < Tout) out[((long)b * C + c) * Tout + t] = tile[tx][i];
+  }
+}
+// dx[b,t,c] = t < Tout ? dout[b,c,t] : 0   for t < T
+__global__ __launch_bounds__(256) void ft_transpose_pad_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx,
+                                                                   int T, int C, int Tout) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < Tout) ? dout[((long)b * C + c) * Tout + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int t = t0 + i, c = c0 + tx;
+    if (t < T && c < C) dx[((long)b * T + t) * C + c] = tile[tx][i];
+  }
+}
+
+// ---- MaskedL1 (trainer/common.py:69-92) on [B,C,T] --------------------------------------------------
+// partial[block] = sum over its elements of |x - target| * (t < len[b])
+__global__ __launch_bounds__(256) void ft_masked_l1_partial_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ target,
+                                                                   const long* __restrict__ lens, int B, int C, int T,
+                                                                   double* __restrict__ partial) {
+  __shared__ double red[4];
+  long total = (long)B * C * T;
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int t = (int)(i % T);
+    int b = (int)(i / ((long)C * T));
+    if (t < lens[b]) acc += (double)fabsf(x[i] - target[i]);
+  }
+  acc = ft_wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// loss = sum(partial) / (C * sum_b min(len_b, T)) ; also stores 1/denominator for the backward
+__global__ void ft_masked_l1_finalize_kernel(const double* __restrict__ partial, int nblocks,
+                                             const long* __restrict__ lens, int B, int C, int T,
+                                             float* __restrict__ loss, float* __restrict__ inv_denom) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblocks; ++i) s += partial[i];
+  double n = 0.0;
+  for (int b = 0; b < B; ++b) {
+    long l = lens[b];
+    if (l < 0) l = 0;
+    if (l > T) l = T;
+    n += (double)l;
+  }
+  n *= (double)C;
+  *loss = (float)(s / n);
+  *inv_denom = (float)(1.0 / n);
+}
+// dx = sign(x - target) * mask * inv_denom * gscale[0]*factor
+__global__ void ft_masked_l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ target,
+                                        const long* __restrict__ lens, const float* __restrict__ inv_denom,
+                                        const float* __restrict__ gout, float factor, float* __restrict__ dx, int B,
+                                        int C, int T) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * C * T;
+  if (i >= total) return;
+  int t = (int)(i % T);
+  int b = (int)(i / ((long)C * T));
+  float g = 0.f;
+  if (t < lens[b]) {
+    float d = x[i] - target[i];
+    float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    g = s * inv_denom[0] * (gout ? gout[0] : 1.f) * factor;
+  }
+  dx[i] = g;
+}
+
 }  // namespace
 
 extern "C" {
@@ -25,6 +261,127 @@ int ft_conv_pack_weight(const float* w, float* wp, int Cout, int Cin, int k, voi
   hipLaunchKernelGGL(ft_pack_conv_w_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout,
                      Cin, k);
   return ft_check_launch("conv_pack_weight");
+}
+
+int ft_dropout(const float* x, float* out, long n, float p, uint64_t seed, void* stream) {
+  FT_REQUIRE(p >= 0.f && p < 1.f, "dropout: p must be in [0,1)");
+  if (n <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_dropout_kernel, dim3(ft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n, p, seed);
+  return ft_check_launch("dropout");
+}
+
+int ft_scale(const float* x, float* out, long n, float s, void* stream) {
+  if (n <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_scale_kernel, dim3(ft_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, n, s);
+  return ft_check_launch("scale");
+}
+
+int ft_embedding_fwd(const long* idx, const float* w, float* out, long rows, int C, int V, int* err_flag,
+                     void* stream) {
+  FT_REQUIRE(rows >= 0 && C >= 0 && V > 0, "embedding_fwd: bad dims");
+  if (rows * C == 0) return FT_OK;
+  hipLaunchKernelGGL(ft_embedding_fwd_kernel, dim3(ft_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, idx, w,
+                     out, rows, C, V, err_flag);
+  return ft_check_launch("embedding_fwd");
+}
+
+int ft_embedding_bwd(const long* idx, const float* dout, float* dw, long rows, int C, int V, void* stream) {
+  FT_REQUIRE(rows >= 0 && C >= 0 && V > 0, "embedding_bwd: bad dims");
+  if (C == 0) return FT_OK;
+  hipLaunchKernelGGL(ft_embedding_bwd_kernel, dim3(V, ft_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, idx, dout,
+                     dw, rows, C);
+  return ft_check_launch("embedding_bwd");
+}
+
+int ft_highway_gate_fwd(const float* x12, const float* x, float* out, long rows, int C, void* stream) {
+  if (rows * C <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_highway_fwd_kernel, dim3(ft_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x12, x,
+                     out, rows, C);
+  return ft_check_launch("highway_gate_fwd");
+}
+
+int ft_highway_gate_bwd(const float* dout, const float* x12, const float* x, float* d12, float* dx, long rows, int C,
+                        void* stream) {
+  if (rows * C <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_highway_bwd_kernel, dim3(ft_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dout, x12,
+                     x, d12, dx, rows, C);
+  return ft_check_launch("highway_gate_bwd");
+}
+
+int ft_maxpool2_fwd(const float* x, float* out, int B, int T, int C, void* stream) {
+  long total = (long)B * T * C;
+  if (total <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_maxpool_fwd_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, T,
+                     C);
+  return ft_check_launch("maxpool2_fwd");
+}
+
+int ft_maxpool2_bwd(const float* dout, const float* x, float* dx, int B, int T, int C, void* stream) {
+  long total = (long)B * T * C;
+  if (total <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_maxpool_bwd_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, x, dx,
+                     B, T, C);
+  return ft_check_launch("maxpool2_bwd");
+}
+
+int ft_cond_add_fwd(const float* x, const float* pitch, const float* energy, const float* w_pitch,
+                    const float* b_pitch, const float* w_energy, const float* b_energy, float pitch_strength,
+                    float energy_strength, float* out, int B, int T, int C, void* stream) {
+  long total = (long)B * T * C;
+  if (total <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_cond_add_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, pitch,
+                     energy, w_pitch, b_pitch, w_energy, b_energy, pitch_strength, energy_strength, out, B, T, C);
+  return ft_check_launch("cond_add_fwd");
+}
+
+int ft_cond_taps(const float* pitch, const float* energy, float* taps, int B, int T, void* stream) {
+  long rows = (long)B * T;
+  if (rows <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_cond_taps_kernel, dim3(ft_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, pitch, energy,
+                     taps, B, T);
+  return ft_check_launch("cond_taps");
+}
+
+int ft_transpose_pad_fwd(const float* x, float* out, int B, int T, int C, int Tout, float pad, void* stream) {
+  if (B <= 0 || C <= 0 || Tout <= 0) return FT_OK;
+  FT_REQUIRE(B <= 65535 && ft_cdiv(C, 32) <= 65535, "transpose_pad_fwd: grid too large");
+  hipLaunchKernelGGL(ft_transpose_pad_kernel, dim3(ft_cdiv(Tout, 32), ft_cdiv(C, 32), B), dim3(256), 0,
+                     (hipStream_t)stream, x, out, T, C, Tout, pad);
+  return ft_check_launch("transpose_pad_fwd");
+}
+
+int ft_transpose_pad_bwd(const float* dout, float* dx, int B, int T, int C, int Tout, void* stream) {
+  if (B <= 0 || C <= 0 || T <= 0) return FT_OK;
+  FT_REQUIRE(B <= 65535 && ft_cdiv(C, 32) <= 65535, "transpose_pad_bwd: grid too large");
+  hipLaunchKernelGGL(ft_transpose_pad_bwd_kernel, dim3(ft_cdiv(T, 32), ft_cdiv(C, 32), B), dim3(256), 0,
+                     (hipStream_t)stream, dout, dx, T, C, Tout);
+  return ft_check_launch("transpose_pad_bwd");
+}
+
+size_t ft_masked_l1_workspace(void) { return 1024 * sizeof(double); }
+
+int ft_masked_l1_fwd(const float* x, const float* target, const long* lens, float* loss, float* inv_denom, int B,
+                     int C, int T, void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(B > 0 && C > 0 && T > 0, "masked_l1_fwd: bad dims");
+  FT_REQUIRE(workspace && workspace_bytes >= ft_masked_l1_workspace(), "masked_l1_fwd: workspace too small");
+  long total = (long)B * C * T;
+  int nb = ft_cdiv(total, 256 * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(ft_masked_l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, target, lens, B, C, T,
+                     (double*)workspace);
+  hipLaunchKernelGGL(ft_masked_l1_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     (const double*)workspace, nb, lens, B, C, T, loss, inv_denom);
+  return ft_check_launch("masked_l1_fwd");
+}
+
+int ft_masked_l1_bwd(const float* x, const float* target, const long* lens, const float* inv_denom,
+                     const float* grad_out, float factor, float* dx, int B, int C, int T, void* stream) {
+  long total = (long)B * C * T;
+  if (total <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_masked_l1_bwd_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, target,
+                     lens, inv_denom, grad_out, factor, dx, B, C, T);
+  return ft_check_launch("masked_l1_bwd");
 }
 
 }  // extern "C"

@@ -173,9 +173,9 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
         if (row >= T.M) continue;
         float* cp = T.C + (long)row * T.ldc + col;
         float v = acc[i][j][e] + bv;
-        if (T.accumulate) v += *cp;
         if (T.relu) v = fmaxf(v, 0.f);
         if (T.scale) v = v * sc + sh;
+        if (T.accumulate) v += *cp;      // residual / gradient accumulation happens last
         *cp = v;
       }
     }

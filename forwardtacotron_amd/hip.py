@@ -139,15 +139,17 @@ def conv_pack_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> tor
 
 
 def conv1d_fwd(x: torch.Tensor, wp: torch.Tensor, relu: bool, Tout: Optional[int] = None,
-               scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [B,T,Cin], wp [k,Cout,Cin] -> y [B,Tout,Cout]"""
+               scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+               accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B,T,Cin], wp [k,Cout,Cin] -> y [B,Tout,Cout]; accumulate_into: result is ADDED onto that tensor"""
     _chk(x, 'x'); _chk(wp, 'wp')
     B, T, Cin = x.shape
     k, Cout, _ = wp.shape
     Tout = T if Tout is None else Tout
-    y = torch.empty(B, Tout, Cout, device=x.device, dtype=x.dtype)
+    y = accumulate_into if accumulate_into is not None else torch.empty(B, Tout, Cout, device=x.device,
+                                                                        dtype=x.dtype)
     _lib.call('ft_conv1d_fwd', _p(x), Cin, _p(wp), _p(scale), _p(shift), _p(y), Cout, B, T, Cin, Cout, k, Tout,
-              int(relu), _stream())
+              int(relu), int(accumulate_into is not None), _stream())
     return y
 
 
@@ -207,3 +209,268 @@ def lr_bwd(dy: torch.Tensor, cum: torch.Tensor, Tx: int) -> torch.Tensor:
     dx = torch.empty(B, Tx, C, device=dy.device, dtype=dy.dtype)
     _lib.call('ft_lr_bwd', _p(dy), _p(cum), _p(dx), B, Tx, Tm, C, _stream())
     return dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# BatchNorm / column sums
+# ---------------------------------------------------------------------------------------------------
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def bn_train_fwd(y: torch.Tensor, gamma, beta, running_mean, running_var, Tout: int, group: int = 0,
+                 residual: Optional[torch.Tensor] = None, momentum: float = BN_MOMENTUM, eps: float = BN_EPS):
+    """y [B,Tbuf,C] -> (out [B,Tout,C], save_mean, save_rstd); running stats updated in place."""
+    _chk(y, 'y')
+    B, Tbuf, C = y.shape
+    out = torch.empty(B, Tout, C, device=y.device, dtype=y.dtype)
+    mean = torch.empty(C, device=y.device, dtype=y.dtype)
+    rstd = torch.empty(C, device=y.device, dtype=y.dtype)
+    nbytes = _lib.query('ft_bn_workspace', B, Tbuf, C)
+    ws = workspace(nbytes, y.device)
+    _lib.call('ft_bn_train_fwd', _p(y), _p(gamma), _p(beta), _p(residual), _p(out), _p(running_mean),
+              _p(running_var), None, _p(mean), _p(rstd), B, Tbuf, Tout, C, group, momentum, eps, _p(ws), ws.numel(),
+              _stream())
+    return out, mean, rstd
+
+
+def bn_bwd(dout: torch.Tensor, y: torch.Tensor, gamma, mean, rstd, group: int, relu: bool):
+    """-> (dy [B,Tbuf,C], dgamma [C], dbeta [C])"""
+    _chk(dout, 'dout'); _chk(y, 'y')
+    B, Tbuf, C = y.shape
+    Tout = dout.shape[1]
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, device=y.device, dtype=y.dtype)
+    dbeta = torch.empty(C, device=y.device, dtype=y.dtype)
+    nbytes = _lib.query('ft_bn_workspace', B, Tbuf, C)
+    ws = workspace(nbytes, y.device)
+    _lib.call('ft_bn_bwd', _p(dout), _p(y), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dgamma), _p(dbeta), B, Tbuf,
+              Tout, C, group, int(relu), _p(ws), ws.numel(), _stream())
+    return dy, dgamma, dbeta
+
+
+def bn_fold_eval(gamma, beta, running_mean, running_var, eps: float = BN_EPS):
+    C = gamma.numel()
+    scale = torch.empty(C, device=gamma.device, dtype=gamma.dtype)
+    shift = torch.empty(C, device=gamma.device, dtype=gamma.dtype)
+    _lib.call('ft_bn_fold_eval', _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(scale), _p(shift),
+              C, _stream())
+    return scale, shift
+
+
+def colsum_raw(x_ptr: int, ldx: int, out: torch.Tensor, rows: int, C: int, scale: float = 1.0,
+               accumulate: bool = False) -> None:
+    nbytes = _lib.query('ft_colsum_workspace', rows, C)
+    ws = workspace(nbytes, out.device)
+    _lib.call('ft_colsum', x_ptr, ldx, _p(out), rows, C, scale, int(accumulate), _p(ws), ws.numel(), _stream())
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, 'x')
+    C = x.shape[-1]
+    rows = x.numel() // max(C, 1)
+    out = torch.empty(C, device=x.device, dtype=x.dtype)
+    colsum_raw(_p(x), C, out, rows, C)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# element-wise
+# ---------------------------------------------------------------------------------------------------
+def dropout(x: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    _chk(x, 'x')
+    out = torch.empty_like(x)
+    _lib.call('ft_dropout', _p(x), _p(out), x.numel(), p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    return out
+
+
+def scale(x: torch.Tensor, s: float) -> torch.Tensor:
+    _chk(x, 'x')
+    out = torch.empty_like(x)
+    _lib.call('ft_scale', _p(x), _p(out), x.numel(), s, _stream())
+    return out
+
+
+
+def embedding_fwd(idx: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    _chk(idx, 'idx', torch.int64); _chk(w, 'w')
+    V, C = w.shape
+    out = torch.empty(*idx.shape, C, device=w.device, dtype=w.dtype)
+    err = _err_flag(w.device)
+    _lib.call('ft_embedding_fwd', _p(idx), _p(w), _p(out), idx.numel(), C, V, _p(err), _stream())
+    return out
+
+
+_err_flags = {}
+
+
+def _err_flag(device) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    if key not in _err_flags:
+        _err_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _err_flags[key]
+
+
+def check_index_errors(device) -> None:
+    """Host-side check of the out-of-range embedding index flag (syncs)."""
+    f = _err_flag(device)
+    if int(f.item()) != 0:
+        f.zero_()
+        raise IndexError('embedding index out of range (set by ft_embedding_fwd)')
+
+
+def embedding_bwd(idx: torch.Tensor, dout: torch.Tensor, V: int) -> torch.Tensor:
+    _chk(idx, 'idx', torch.int64); _chk(dout, 'dout')
+    C = dout.shape[-1]
+    dw = torch.empty(V, C, device=dout.device, dtype=dout.dtype)
+    _lib.call('ft_embedding_bwd', _p(idx), _p(dout), _p(dw), idx.numel(), C, V, _stream())
+    return dw
+
+
+def highway_gate_fwd(x12: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    _chk(x12, 'x12'); _chk(x, 'x')
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _lib.call('ft_highway_gate_fwd', _p(x12), _p(x), _p(out), x.numel() // C, C, _stream())
+    return out
+
+
+def highway_gate_bwd(dout, x12, x):
+    _chk(dout, 'dout')
+    C = x.shape[-1]
+    d12 = torch.empty_like(x12)
+    dx = torch.empty_like(x)
+    _lib.call('ft_highway_gate_bwd', _p(dout), _p(x12), _p(x), _p(d12), _p(dx), x.numel() // C, C, _stream())
+    return d12, dx
+
+
+def maxpool2_fwd(x: torch.Tensor) -> torch.Tensor:
+    _chk(x, 'x')
+    B, T, C = x.shape
+    out = torch.empty_like(x)
+    _lib.call('ft_maxpool2_fwd', _p(x), _p(out), B, T, C, _stream())
+    return out
+
+
+def maxpool2_bwd(dout: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    _chk(dout, 'dout')
+    B, T, C = x.shape
+    dx = torch.empty_like(x)
+    _lib.call('ft_maxpool2_bwd', _p(dout), _p(x), _p(dx), B, T, C, _stream())
+    return dx
+
+
+def cond_add_fwd(x, pitch, energy, wp, bp, we, be, sp: float, se: float) -> torch.Tensor:
+    _chk(x, 'x'); _chk(pitch, 'pitch'); _chk(energy, 'energy')
+    B, T, C = x.shape
+    out = torch.empty_like(x)
+    _lib.call('ft_cond_add_fwd', _p(x), _p(pitch), _p(energy), _p(wp), _p(bp), _p(we), _p(be), sp, se, _p(out), B,
+              T, C, _stream())
+    return out
+
+
+def cond_taps(pitch, energy) -> torch.Tensor:
+    B, T = pitch.shape
+    taps = torch.empty(B, T, 8, device=pitch.device, dtype=pitch.dtype)
+    _lib.call('ft_cond_taps', _p(pitch), _p(energy), _p(taps), B, T, _stream())
+    return taps
+
+
+def transpose_pad_fwd(x: torch.Tensor, Tout: int, pad: float) -> torch.Tensor:
+    _chk(x, 'x')
+    B, T, C = x.shape
+    out = torch.empty(B, C, Tout, device=x.device, dtype=x.dtype)
+    _lib.call('ft_transpose_pad_fwd', _p(x), _p(out), B, T, C, Tout, pad, _stream())
+    return out
+
+
+def transpose_pad_bwd(dout: torch.Tensor, T: int) -> torch.Tensor:
+    _chk(dout, 'dout')
+    B, C, Tout = dout.shape
+    dx = torch.empty(B, T, C, device=dout.device, dtype=dout.dtype)
+    _lib.call('ft_transpose_pad_bwd', _p(dout), _p(dx), B, T, C, Tout, _stream())
+    return dx
+
+
+def transpose2d(x: torch.Tensor) -> torch.Tensor:
+    """[R,C] -> [C,R] (used for W_hh^T in BPTT)."""
+    R, C = x.shape
+    return transpose_pad_fwd(x.view(1, R, C), R, 0.0).view(C, R)
+
+
+def masked_l1_fwd(x: torch.Tensor, target: torch.Tensor, lens: torch.Tensor):
+    _chk(x, 'x'); _chk(target, 'target'); _chk(lens, 'lens', torch.int64)
+    B, C, T = x.shape
+    loss = torch.empty((), device=x.device, dtype=x.dtype)
+    inv = torch.empty(1, device=x.device, dtype=x.dtype)
+    ws = workspace(_lib.query('ft_masked_l1_workspace'), x.device)
+    _lib.call('ft_masked_l1_fwd', _p(x), _p(target), _p(lens), _p(loss), _p(inv), B, C, T, _p(ws), ws.numel(),
+              _stream())
+    return loss, inv
+
+
+def masked_l1_bwd(x, target, lens, inv, grad_out: Optional[torch.Tensor], factor: float = 1.0) -> torch.Tensor:
+    B, C, T = x.shape
+    dx = torch.empty_like(x)
+    _lib.call('ft_masked_l1_bwd', _p(x), _p(target), _p(lens), _p(inv), _p(grad_out), factor, _p(dx), B, C, T,
+              _stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------
+# recurrences
+# ---------------------------------------------------------------------------------------------------
+def gru_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool):
+    _chk(xp, 'xp')
+    B, T, _ = xp.shape
+    out = torch.empty(B, T, 2 * H, device=xp.device, dtype=xp.dtype)
+    gates = torch.empty(B, T, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
+    _lib.call('ft_gru_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(out), _p(gates), B, T, H,
+              _stream())
+    return out, gates
+
+
+def gru_bwd(dout, out, gates, whhT_f, whhT_r, H: int):
+    _chk(dout, 'dout')
+    B, T, _ = out.shape
+    dxp = torch.empty(B, T, 6 * H, device=out.device, dtype=out.dtype)
+    dhp = torch.empty(B, T, 6 * H, device=out.device, dtype=out.dtype)
+    carry = torch.empty(B, 2, H, device=out.device, dtype=out.dtype)
+    _lib.call('ft_gru_bwd', _p(dout), _p(out), _p(gates), _p(whhT_f), _p(whhT_r), _p(dxp), _p(dhp), _p(carry), B, T,
+              H, _stream())
+    return dxp, dhp
+
+
+def lstm_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, lens: Optional[torch.Tensor], H: int, save_gates: bool):
+    _chk(xp, 'xp')
+    B, T, _ = xp.shape
+    raw = torch.empty(B, T, 2 * H, device=xp.device, dtype=xp.dtype)
+    cst = torch.empty(B, T, 2 * H, device=xp.device, dtype=xp.dtype)
+    gates = torch.empty(B, T, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
+    _lib.call('ft_lstm_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(lens), _p(raw), _p(cst),
+              _p(gates), B, T, H, _stream())
+    return raw, cst, gates
+
+
+def lstm_bwd(dout, raw, cst, gates, whhT_f, whhT_r, lens: Optional[torch.Tensor], H: int):
+    _chk(dout, 'dout')
+    B, T, _ = raw.shape
+    dg = torch.empty(B, T, 8 * H, device=raw.device, dtype=raw.dtype)
+    carry = torch.empty(B, 2, H, device=raw.device, dtype=raw.dtype)
+    _lib.call('ft_lstm_bwd', _p(dout), _p(raw), _p(cst), _p(gates), _p(whhT_f), _p(whhT_r), _p(lens), _p(dg),
+              _p(carry), B, T, H, _stream())
+    return dg
+
+
+def fill_padded(raw: torch.Tensor, lens: torch.Tensor, pad: float) -> torch.Tensor:
+    B, T, C = raw.shape
+    out = torch.empty_like(raw)
+    _lib.call('ft_fill_padded', _p(raw), _p(lens), _p(out), B, T, C, pad, _stream())
+    return out
+
+
+def mask_rows(src: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+    B, T, C = src.shape
+    dst = torch.empty_like(src)
+    _lib.call('ft_mask_rows', _p(src), _p(lens), _p(dst), B, T, C, _stream())
+    return dst

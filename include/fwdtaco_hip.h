@@ -52,10 +52,12 @@ int ft_linear_bwd_weight(const float* dy, long lddy, const float* x, long ldx, f
 /* ---- nn.Conv1d(stride 1, padding k//2, bias=False) of BatchNormConv (common_layers.py:50,55-56) ------ */
 /* weights are consumed TAP-MAJOR: wp[k][Cout][Cin] (ft_conv_pack_weight from torch's [Cout][Cin][k]).
  * y[b,t',co] = relu?( sum_j sum_ci x[b, t'+j-k/2, ci] * w[co,ci,j] ) (* scale[co] + shift[co] if scale) for
- * t' in [0,Tout); Tout = T (odd k, or even k sliced as the CBHG does, common_layers.py:99) or T+1 (even k). */
+ * t' in [0,Tout); Tout = T (odd k, or even k sliced as the CBHG does, common_layers.py:99) or T+1 (even k);
+ * accumulate=1 adds the result onto y (residual connection, common_layers.py:114). */
 int ft_conv_pack_weight(const float* w, float* wp, int Cout, int Cin, int k, void* stream);
 int ft_conv1d_fwd(const float* x, long ldx, const float* wp, const float* scale, const float* shift, float* y,
-                  long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, void* stream);
+                  long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, int accumulate,
+                  void* stream);
 /* CBHG conv1d_bank (common_layers.py:72-76,97-102): members k=1..K (K<=16) in ONE launch; member i writes
  * ybank[:, :, i*C:(i+1)*C] of ybank[B,Tout,K*C]; wp_all = packed member weights back to back. */
 int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float* scale, const float* shift,
@@ -78,6 +80,92 @@ int ft_lr_expand(const float* x, const int* cum, float* y, int* src_idx, int B, 
                  void* stream);
 /* dx[b,j,:] = sum of dy rows of token j (fixed order) */
 int ft_lr_bwd(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, void* stream);
+
+/* ---- nn.BatchNorm1d of BatchNormConv (common_layers.py:51,57) on channels-last y[B,Tbuf,C] ----------- */
+/* group > 0 = CBHG bank buffer [B,T+1,K*group]: channel c belongs to kernel size k=c/group+1 and has
+ * Tbuf-1 valid rows for odd k, Tbuf for even k (common_layers.py:97-99); group = 0: all Tbuf rows valid.
+ * train fwd: batch statistics (biased var) over valid rows -> save_mean/save_rstd; running stats updated
+ * in place (momentum, unbiased var), *num_batches_tracked += 1; out[B,Tout,C] = bn(y)[:, :Tout] (+residual). */
+size_t ft_bn_workspace(int B, int Tbuf, int C);
+int ft_bn_train_fwd(const float* y, const float* gamma, const float* beta, const float* residual, float* out,
+                    float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
+                    float* save_rstd, int B, int Tbuf, int Tout, int C, int group, float momentum, float eps,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* dy[B,Tbuf,C] (0 on invalid rows), dgamma, dbeta from dout[B,Tout,C]; relu=1 also applies the ReLU mask
+ * (y>0) of the conv->ReLU->BN order (common_layers.py:55-57) */
+int ft_bn_bwd(const float* dout, const float* y, const float* gamma, const float* save_mean, const float* save_rstd,
+              float* dy, float* dgamma, float* dbeta, int B, int Tbuf, int Tout, int C, int group, int relu,
+              void* workspace, size_t workspace_bytes, void* stream);
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale (fed to the conv epilogue) */
+int ft_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                    float eps, float* scale, float* shift, int C, void* stream);
+/* out[c] (+)= scale * sum_rows x[row*ldx + c]   (bias gradients; ordered, reproducible) */
+size_t ft_colsum_workspace(int rows, int C);
+int ft_colsum(const float* x, long ldx, float* out, int rows, int C, float scale, int accumulate, void* workspace,
+              size_t workspace_bytes, void* stream);
+
+/* ---- F.dropout (forward_tacotron.py:35 ; common_layers.py:106,110) and scalar scale (x/alpha, :39) ----- */
+/* out = keep ? x/(1-p) : 0 with keep(i) = hash(seed,i) >= p; calling it on the gradient with the same seed
+ * is the backward (no mask tensor).  torch's RNG stream cannot be matched: parity runs use p = 0. */
+int ft_dropout(const float* x, float* out, long n, float p, uint64_t seed, void* stream);
+int ft_scale(const float* x, float* out, long n, float s, void* stream);
+
+/* ---- nn.Embedding (forward_tacotron.py:18,31,73,133) -------------------------------------------------- */
+/* out[row,:] = w[idx[row],:] ; *err_flag set to 1 on an out-of-range index (row zero-filled) */
+int ft_embedding_fwd(const long* idx, const float* w, float* out, long rows, int C, int V, int* err_flag,
+                     void* stream);
+int ft_embedding_bwd(const long* idx, const float* dout, float* dw, long rows, int C, int V, void* stream);
+
+/* ---- HighwayNetwork gate (common_layers.py:35-40); x12 = [W1 x + b1 | W2 x + b2] from ft_linear_multi_fwd */
+int ft_highway_gate_fwd(const float* x12, const float* x, float* out, long rows, int C, void* stream);
+/* d12 = gradient wrt x12, dx = direct-path gradient dout*(1-g) (caller adds d12*[W1;W2]) */
+int ft_highway_gate_bwd(const float* dout, const float* x12, const float* x, float* d12, float* dx, long rows, int C,
+                        void* stream);
+
+/* ---- MaxPool1d(kernel 2, stride 1, padding 1)[:T] (common_layers.py:78,105): out[t]=max(x[t-1],x[t]) ---- */
+int ft_maxpool2_fwd(const float* x, float* out, int B, int T, int C, void* stream);
+int ft_maxpool2_bwd(const float* dout, const float* x, float* dx, int B, int T, int C, void* stream);
+
+/* ---- pitch/energy conditioning (forward_tacotron.py:111-112,137-143): Conv1d(1->C,k3,p1)+bias, scaled add */
+int ft_cond_add_fwd(const float* x, const float* pitch, const float* energy, const float* w_pitch,
+                    const float* b_pitch, const float* w_energy, const float* b_energy, float pitch_strength,
+                    float energy_strength, float* out, int B, int T, int C, void* stream);
+/* taps[row][8] = [p[t-1],p[t],p[t+1],1,e[t-1],e[t],e[t+1],1]; weight/bias grads = dy^T taps (ft_linear_bwd_weight) */
+int ft_cond_taps(const float* pitch, const float* energy, float* taps, int B, int T, void* stream);
+
+/* ---- output layout + ForwardTacotron._pad (forward_tacotron.py:155,159,161-162,236-239) ---------------- */
+/* out[b,c,t] = t < T ? x[b,t,c] : pad, t < Tout   ([B,T,C] -> [B,C,Tout]) ; bwd is the masked transpose back */
+int ft_transpose_pad_fwd(const float* x, float* out, int B, int T, int C, int Tout, float pad, void* stream);
+int ft_transpose_pad_bwd(const float* dout, float* dx, int B, int T, int C, int Tout, void* stream);
+
+/* ---- MaskedL1 (trainer/common.py:69-92) on [B,C,T] with int64 lens ----------------------------------- */
+size_t ft_masked_l1_workspace(void);
+int ft_masked_l1_fwd(const float* x, const float* target, const long* lens, float* loss, float* inv_denom, int B,
+                     int C, int T, void* workspace, size_t workspace_bytes, void* stream);
+/* dx = sign(x-target)*mask*inv_denom * factor * (grad_out ? grad_out[0] : 1) */
+int ft_masked_l1_bwd(const float* x, const float* target, const long* lens, const float* inv_denom,
+                     const float* grad_out, float factor, float* dx, int B, int C, int T, void* stream);
+
+/* ---- nn.GRU(bidirectional, batch_first), h0 = 0 (common_layers.py:89,123 ; forward_tacotron.py:24,37) - */
+/* xp[B,T,2*3H] = x W_ih^T + b_ih (dir 0 | dir 1); out[B,T,2H]; gates[B,T,2,4H] = (r,z,n,W_hn h+b_hn) or NULL */
+int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
+               float* out, float* gates, int B, int T, int H, void* stream);
+/* BPTT: whhT = W_hh^T [H,3H]; dxp / dhp [B,T,2*3H] = d(pre-activations) wrt input / hidden projections;
+ * carry [B,2,H] scratch.  Weight grads follow from ft_linear_bwd_weight on dxp / dhp. */
+int ft_gru_bwd(const float* dout, const float* out, const float* gates, const float* whhT_f, const float* whhT_r,
+               float* dxp, float* dhp, float* carry, int B, int T, int H, void* stream);
+
+/* ---- pack_padded_sequence -> nn.LSTM(bidirectional) -> pad_packed_sequence (forward_tacotron.py:96-99,147-152)
+ * lens (int64 [B], device) or NULL = run over the padded length (generate path, :224).  Item b is processed
+ * over exactly lens[b] frames in both directions; out_raw / cstate [B,T,2H] are ZERO at t >= lens[b];
+ * ft_fill_padded then writes the padding_value the reference's unpack inserts. xp includes b_ih; b_hh added here. */
+int ft_lstm_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
+                const long* lens, float* out_raw, float* cstate, float* gates, int B, int T, int H, void* stream);
+int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, const float* gates,
+                const float* whhT_f, const float* whhT_r, const long* lens, float* dgates, float* carry, int B, int T,
+                int H, void* stream);
+int ft_fill_padded(const float* raw, const long* lens, float* out, int B, int T, int C, float pad, void* stream);
+int ft_mask_rows(const float* src, const long* lens, float* dst, int B, int T, int C, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,10 +104,11 @@ def batchnorm_conv(x: Tensor, P: Dict[str, Tensor], prefix: str, relu: bool,
 
 def maxpool_k2s1p1(x: Tensor) -> Tensor:
     """MaxPool1d(kernel 2, stride 1, padding 1)[:, :, :T]  (common_layers.py:78,105):
-    out[t] = max(x[t-1], x[t]) with x[-1] = -inf."""
+    out[t] = max(x[t-1], x[t]) with x[-1] = -inf.  torch's max_pool keeps the FIRST maximal element
+    of a window (strict '>' update), which decides where the gradient goes on ties (post-ReLU zeros)."""
     prev = torch.full_like(x, -float('inf'))
     prev[:, :, 1:] = x[:, :, :-1]
-    return torch.maximum(prev, x)
+    return torch.where(x > prev, x, prev)
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:

@@ -1,0 +1,306 @@
+"""GPU parity of the drop-in module (forward, losses, every gradient) against
+  (a) golden fixtures captured from the imported reference (tests/golden/*.npz) and
+  (b) the CPU oracle on seeded inputs, including deliberately awkward layer sizes.
+Tolerances: fp32 forward 1e-4 abs on mel (north_star), tighter where the graph is short."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import TINY, ODD, TRAIN_CFG, load_npz, sub, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ft():
+    import forwardtacotron_amd as pkg
+    from forwardtacotron_amd import model, ops, hip
+    assert torch.cuda.is_available()
+    return model, ops, hip
+
+
+def cuda_batch(batch):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def load_sd(mod, sd):
+    mod.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    return mod
+
+
+# --------------------------------------------------------------------------------------------------- layers
+@pytest.mark.parametrize('tag,relu', [('bnc_k5', True), ('bnc_k4', True), ('bnc_k3_norelu', False),
+                                      ('bnc_k1', True), ('bnc_k2', True)])
+def test_batchnorm_conv_golden(ft, tag, relu):
+    model, ops, hip = ft
+    L = load_npz('layers.npz')
+    sd = sub(L, tag + '/sd/')
+    Cout, Cin, k = sd['conv.weight'].shape
+    m = load_sd(model.BatchNormConv(Cin, Cout, k, relu=relu), sd).cuda()
+    x_bct = torch.from_numpy(L[tag + '/x'])
+    x = x_bct.transpose(1, 2).contiguous().cuda()
+    T = x.shape[1]
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+    assert maxdiff(y.cpu().transpose(1, 2), L[tag + '/eval'][:, :, :T]) < 1e-5
+    m.train()
+    xg = x.clone().requires_grad_(True)
+    y = m(xg)
+    ref = torch.from_numpy(L[tag + '/train'])
+    assert maxdiff(y.detach().cpu().transpose(1, 2), ref[:, :, :T]) < 1e-5
+    w = torch.from_numpy(L[tag + '/w'])
+    if ref.shape[2] == T:      # odd k: full gradient check against the reference's autograd
+        (y * w.transpose(1, 2).cuda()).sum().backward()
+        assert maxdiff(xg.grad.cpu().transpose(1, 2), L[tag + '/dx']) < 2e-5
+        assert maxdiff(m.conv.weight.grad.cpu(), L[tag + '/dW']) < 2e-5
+        assert maxdiff(m.bnorm.weight.grad.cpu(), L[tag + '/dgamma']) < 2e-5
+        assert maxdiff(m.bnorm.bias.grad.cpu(), L[tag + '/dbeta']) < 2e-5
+    after = sub(L, tag + '/sd_after/')
+    assert maxdiff(m.bnorm.running_mean.cpu(), after['bnorm.running_mean']) < 1e-6
+    assert maxdiff(m.bnorm.running_var.cpu(), after['bnorm.running_var']) < 1e-6
+
+
+def test_maxpool_highway_golden(ft):
+    model, ops, hip = ft
+    L = load_npz('layers.npz')
+    x = torch.from_numpy(L['maxpool/x']).transpose(1, 2).contiguous().cuda()
+    assert maxdiff(hip.maxpool2_fwd(x).cpu().transpose(1, 2), L['maxpool/y']) == 0.0
+    h = load_sd(model.HighwayNetwork(6), sub(L, 'highway/sd/')).cuda()
+    y = h(torch.from_numpy(L['highway/x']).cuda())
+    assert maxdiff(y.detach().cpu(), L['highway/y']) < 2e-6
+
+
+def test_maxpool_backward_first_max_wins(ft):
+    model, ops, hip = ft
+    # ties (post-ReLU zeros are common): torch routes the gradient to the FIRST maximal element
+    x = torch.tensor([[[1.], [1.], [0.], [2.], [2.], [2.], [-1.]]])          # [1,7,1]
+    mp = torch.nn.MaxPool1d(2, 1, 1)
+    xr = x.transpose(1, 2).clone().requires_grad_(True)
+    g = torch.arange(1., 8.).view(1, 1, 7)
+    (mp(xr)[:, :, :7] * g).sum().backward()
+    dx = hip.maxpool2_bwd(g.transpose(1, 2).contiguous().cuda(), x.cuda())
+    assert maxdiff(dx.cpu().transpose(1, 2), xr.grad) == 0.0
+
+
+def test_bigru_golden_and_grads(ft):
+    model, ops, hip = ft
+    from oracle import ft_oracle as O
+    L = load_npz('layers.npz')
+    sd = sub(L, 'gru/sd/')
+    g = load_sd(model.GRU(5, 4), sd).cuda()
+    x = torch.from_numpy(L['gru/x'])
+    xg = x.cuda().requires_grad_(True)
+    y = g(xg)
+    assert maxdiff(y.detach().cpu(), L['gru/y']) < 2e-6
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(1))
+    (y * w.cuda()).sum().backward()
+    xo = x.double().requires_grad_(True)
+    Po = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    (O.bigru(xo, Po, '') * w.double()).sum().backward()
+    assert maxdiff(xg.grad.cpu(), xo.grad) < 2e-5
+    for k in sd:
+        assert maxdiff(getattr(g, k).grad.cpu(), Po[k].grad) < 2e-5, k
+
+
+def test_bilstm_golden_and_grads(ft):
+    model, ops, hip = ft
+    from oracle import ft_oracle as O
+    L = load_npz('layers.npz')
+    sd = sub(L, 'lstm/sd/')
+    m = load_sd(model.LSTM(5, 6), sd).cuda()
+    x = torch.from_numpy(L['lstm/x'])
+    lens = torch.from_numpy(L['lstm/lens'])
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg, lens.cuda(), -11.5129)
+    assert maxdiff(y.detach().cpu(), L['lstm/y_packed']) < 2e-6
+    assert maxdiff(m(x.cuda(), None, 0.0).detach().cpu(), L['lstm/y_full']) < 2e-6
+    w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+    (y * w.cuda()).sum().backward()
+    xo = x.double().requires_grad_(True)
+    Po = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    (O.bilstm(xo, lens, Po, '') * w.double()).sum().backward()
+    assert maxdiff(xg.grad.cpu(), xo.grad) < 2e-5
+    for k in sd:
+        assert maxdiff(getattr(m, k).grad.cpu(), Po[k].grad) < 2e-5, k
+
+
+def test_cbhg_golden(ft):
+    model, ops, hip = ft
+    L = load_npz('layers.npz')
+    c = load_sd(model.CBHG(K=4, in_channels=6, channels=8, proj_channels=[8, 6], num_highways=2, dropout=0.),
+                sub(L, 'cbhg/sd/')).cuda()
+    x = torch.from_numpy(L['cbhg/x']).transpose(1, 2).contiguous().cuda()
+    c.eval()
+    with torch.no_grad():
+        assert maxdiff(c(x).cpu(), L['cbhg/eval']) < 1e-5
+    c.train()
+    assert maxdiff(c(x).detach().cpu(), L['cbhg/train']) < 1e-5
+
+
+def test_series_predictor_golden(ft):
+    model, ops, hip = ft
+    L = load_npz('layers.npz')
+    sp = load_sd(model.SeriesPredictor(num_chars=20, emb_dim=4, conv_dims=6, rnn_dims=3, dropout=0.),
+                 sub(L, 'sp/sd/')).cuda()
+    sp.eval()
+    with torch.no_grad():
+        y = sp(torch.from_numpy(L['sp/x']).cuda(), alpha=2.0)
+    assert maxdiff(y.cpu(), L['sp/eval_alpha2']) < 1e-5
+
+
+def test_masked_l1_golden(ft):
+    model, ops, hip = ft
+    L = load_npz('layers.npz')
+    x = torch.from_numpy(L['l1/x']).cuda().requires_grad_(True)
+    t = torch.from_numpy(L['l1/t']).cuda()
+    lens = torch.from_numpy(L['l1/lens']).cuda()
+    loss = ops.masked_l1(x, t, lens)
+    assert abs(float(loss) - float(L['l1/loss'])) < 1e-6
+    (loss * 3.0).backward()
+    from oracle import ft_oracle as O
+    xo = torch.from_numpy(L['l1/x']).requires_grad_(True)
+    (O.masked_l1(xo, torch.from_numpy(L['l1/t']), torch.from_numpy(L['l1/lens'])) * 3.0).backward()
+    assert maxdiff(x.grad.cpu(), xo.grad) < 1e-7
+
+
+# --------------------------------------------------------------------------------------------------- model
+def _train_step_hip(model_mod, ops, m, batch, train_cfg):
+    m.train()
+    b = cuda_batch({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+    pitch_t = b['pitch'].detach().clone()
+    energy_t = b['energy'].detach().clone()
+    pred = m(b)
+    m1 = ops.masked_l1(pred['mel'], b['mel'], b['mel_len'])
+    m2 = ops.masked_l1(pred['mel_post'], b['mel'], b['mel_len'])
+    dl = ops.masked_l1(pred['dur'].unsqueeze(1), b['dur'].unsqueeze(1), b['x_len'])
+    pl = ops.masked_l1(pred['pitch'], pitch_t.unsqueeze(1), b['x_len'])
+    el = ops.masked_l1(pred['energy'], energy_t.unsqueeze(1), b['x_len'])
+    loss = m1 + m2 + train_cfg['dur_loss_factor'] * dl + train_cfg['pitch_loss_factor'] * pl \
+        + train_cfg['energy_loss_factor'] * el
+    for p in m.parameters():
+        p.grad = None
+    loss.backward()
+    return pred, {'loss': loss, 'mel': m1, 'mel_post': m2, 'dur': dl, 'pitch': pl, 'energy': el}, b
+
+
+def test_tiny_model_golden_eval_and_train(ft):
+    model, ops, hip = ft
+    M = load_npz('tiny_model.npz')
+    m = load_sd(model.ForwardTacotron(**TINY), sub(M, 'sd/')).cuda()
+    batch = sub(M, 'batch/')
+    m.eval()
+    with torch.no_grad():
+        pred = m(cuda_batch({k: v.clone() for k, v in batch.items()}))
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+        assert pred[k].shape == M['eval/' + k].shape, k
+        assert maxdiff(pred[k].cpu(), M['eval/' + k]) < 5e-5, k
+    pred, L, b = _train_step_hip(model, ops, m, batch, TRAIN_CFG)
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+        assert maxdiff(pred[k].detach().cpu(), M['train/' + k]) < 5e-5, k
+    for k, gk in (('loss', 'total'), ('mel', 'mel'), ('mel_post', 'mel_post'), ('dur', 'dur'),
+                  ('pitch', 'pitch'), ('energy', 'energy')):
+        assert abs(float(L[k]) - float(M['loss/' + gk])) < 2e-5, k
+    worst, worst_k = 0.0, None
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        d = maxdiff(p.grad.cpu(), M['grad/' + k])
+        if d > worst:
+            worst, worst_k = d, k
+    assert worst < 1e-4, (worst, worst_k)
+    # buffers after the training forward: BN running stats, counters, step
+    after = sub(M, 'sd_after/')
+    sd = m.state_dict()
+    for k, v in after.items():
+        if 'running_' in k:
+            assert maxdiff(sd[k].cpu(), v) < 1e-5, k
+        elif k.endswith('num_batches_tracked') or k == 'step':
+            assert int(sd[k].reshape(-1)[0]) == int(v.reshape(-1)[0]), k
+    assert np.array_equal(b['dur'].cpu().numpy(), np.maximum(M['batch/dur'], 0))   # in-place clamp side effect
+
+
+@pytest.mark.parametrize('cfg_name', ['tiny', 'odd'])
+def test_model_vs_oracle_train(ft, cfg_name):
+    model, ops, hip = ft
+    from oracle import ft_oracle as O
+    cfg = TINY if cfg_name == 'tiny' else ODD
+    torch.manual_seed(11)
+    m = model.ForwardTacotron(**cfg)
+    g = torch.Generator().manual_seed(5)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm1d):
+            mod.weight.data = 1 + 0.2 * torch.randn(mod.weight.shape, generator=g)
+            mod.bias.data = 0.1 * torch.randn(mod.bias.shape, generator=g)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    batch = O.synthetic_batch(B=5, Tmax=13, n_mels=cfg['n_mels'], max_dur=5, seed=3)
+    batch['dur'][1, 2] = -1.0          # negative duration: clamped in place by the LengthRegulator
+    batch['dur'][2, :3] = 0.0
+    # recompute mel_len/mel so that sum(dur) == mel_len still holds after the edits
+    r = torch.from_numpy(O.lr_repeats(batch['dur'].numpy()))
+    batch['mel_len'] = r.sum(1)
+    Tm = int(batch['mel_len'].max())
+    mel = torch.full((5, cfg['n_mels'], Tm + 1), -11.5129)
+    for b in range(5):
+        n = int(batch['mel_len'][b])
+        mel[b, :, :n] = torch.randn(cfg['n_mels'], n, generator=g) * 2 - 5
+    batch['mel'] = mel
+    newP, _, info = O.train_step(P, {}, {k: v.clone() for k, v in batch.items()}, cfg, TRAIN_CFG, 1e-3, 1)
+    m = m.cuda()
+    pred, L, _ = _train_step_hip(model, ops, m, batch, TRAIN_CFG)
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+        assert maxdiff(pred[k].detach().cpu(), info['pred'][k]) < 5e-5, k
+    assert abs(float(L['loss']) - float(info['losses']['loss'])) < 2e-5
+    worst, worst_k = 0.0, None
+    for k, p in m.named_parameters():
+        d = maxdiff(p.grad.cpu(), info['grads'][k])
+        if d > worst:
+            worst, worst_k = d, k
+    assert worst < 1e-4, (worst, worst_k)
+    sd = m.state_dict()
+    for k in sd:
+        if 'running_' in k:
+            assert maxdiff(sd[k].cpu(), newP[k]) < 1e-5, k
+
+
+def test_generate_golden(ft):
+    model, ops, hip = ft
+    G = load_npz('generate.npz')
+    m = load_sd(model.ForwardTacotron(**TINY), sub(G, 'sd/')).cuda()
+    for tag in ('b1', 'b2'):
+        out = m.generate(torch.from_numpy(G[tag + '/x']).cuda(), alpha=0.9)
+        for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+            assert out[k].shape == G[f'{tag}/{k}'].shape, (tag, k)
+            assert maxdiff(out[k].cpu(), G[f'{tag}/{k}']) < 5e-5, (tag, k)
+
+
+def test_reference_unit_test_shapes(ft):
+    """tests/test_forward_tacotron.py:19-46 of the reference, on the full singlespeaker config."""
+    model, ops, hip = ft
+    from helpers import FULL
+    torch.manual_seed(0)
+    m = model.ForwardTacotron(**FULL).cuda()
+    batch = {
+        'dur': torch.full((2, 10), fill_value=2).float(),
+        'mel': torch.ones((2, 80, 20)).float(),
+        'x': torch.ones((2, 10)).long(),
+        'mel_len': torch.full((2,), fill_value=20).long(),
+        'pitch': torch.ones((2, 10)).float(),
+        'energy': torch.ones((2, 10)).float(),
+    }
+    pred = m(cuda_batch(batch))
+    assert set(pred.keys()) == {'mel', 'mel_post', 'dur', 'pitch', 'energy'}
+    assert tuple(pred['mel_post'].shape) == (2, 80, 20)
+    assert tuple(pred['dur'].shape) == (2, 10)
+    assert tuple(pred['pitch'].shape) == (2, 1, 10)
+    assert tuple(pred['energy'].shape) == (2, 1, 10)
+    gen = m.generate(x=torch.ones((1, 10)).long().cuda())
+    assert gen['mel_post'].size(1) == 80 and tuple(gen['dur'].shape) == (1, 10)
+    assert tuple(gen['pitch'].shape) == (1, 1, 10)
+
+
+def test_cpu_tensors_are_refused(ft):
+    model, ops, hip = ft
+    m = model.ForwardTacotron(**TINY)
+    with pytest.raises(Exception):
+        m({'x': torch.ones(1, 3).long(), 'mel': torch.ones(1, 10, 4), 'dur': torch.ones(1, 3),
+           'mel_len': torch.tensor([3]), 'pitch': torch.ones(1, 3), 'energy': torch.ones(1, 3)})
