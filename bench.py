@@ -1,0 +1,168 @@
+"""bench.py -- mel-frames/s of one full ForwardTacotron train step on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = forward + 5 MaskedL1 losses + backward + clip_grad_norm(1.0) + Adam (+ bucketed RCCL all-reduce
+when N > 1) on the LJSpeech-shaped synthetic batch of SURVEY.md section 8d (bs=32 per GPU, Tx=128,
+Tm=841, 19,320 valid frames on rank 0's seed), singlespeaker.yaml model, fp32, dropout at config values,
+inputs resident in HBM before the timed region.  Weak scaling: every rank draws its own bs=32 batch.
+
+Rank 0 prints ONE JSON line (driver contract) with two extra objects:
+  roofline     : exact-f32 MFMA roofline of the dominant kernel (the f32-MFMA GEMM/conv kernel), timed live
+                 with HIP events on the launch stream, plus whole-step achieved TFLOP/s in `step`
+  cpu_baseline : the CPU oracle (port of the reference step) timed on this box's host cores on a bounded
+                 sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def dominant_kernel_roofline(device):
+    """Times the dominant GEMM-shaped launch of the step -- the postnet conv bank forward
+    (M = 32*842 rows, 8 members k=1..8, Cin 80 -> 256: 2*B*T*80*256*36 FLOP) -- with HIP events."""
+    from forwardtacotron_amd import hip as H
+    B, T, Cin, C, K = 32, 841, 80, 256, 8
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, Cin, generator=g).to(device)
+    wp_all = (torch.randn(C * Cin * K * (K + 1) // 2, generator=g) * 0.05).to(device)
+    for _ in range(3):
+        H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T + 1)
+    reps = 10
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T + 1)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    flops = 2.0 * B * (T + 1) * Cin * C * (K * (K + 1) // 2)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'ft_gemm_rows_kernel<2,2,NT> (postnet conv bank fwd)',
+            'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+            'launch_ms': round(ms, 4), 'flops_per_launch': flops}
+
+
+def cpu_baseline(model_cfg, train_cfg):
+    """Oracle (CPU port of the reference train step) on a bounded sample: B=2 items of the same shape."""
+    from oracle import ft_oracle as O       # checker / baseline leg only
+    from forwardtacotron_amd.model import ForwardTacotron
+    torch.manual_seed(0)
+    m = ForwardTacotron(**model_cfg)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    batch = O.synthetic_batch(B=2, Tmax=128, n_mels=model_cfg['n_mels'], seed=0)
+    n_frm = int(batch['mel_len'].sum())
+    t0 = time.time()
+    O.train_step(P, {}, batch, model_cfg, train_cfg, lr=5e-5, step_count=1)
+    dt = time.time() - t0
+    return {'value': round(n_frm / dt, 1), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 train step, B=2 of the bs=32 workload ({n_frm} frames, {dt:.1f} s), '
+                      f'oracle/ft_oracle.py on {os.cpu_count()} host cpus'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from forwardtacotron_amd import data
+    from forwardtacotron_amd.model import ForwardTacotron
+    from forwardtacotron_amd.trainer import TrainStep
+
+    model_cfg = dict(data.SINGLESPEAKER_MODEL)
+    train_cfg = dict(data.SINGLESPEAKER_TRAIN)
+    torch.manual_seed(0)                      # identical initial weights on every rank
+    model = ForwardTacotron(**model_cfg).to(device)
+    ts = TrainStep(model, lr=5e-5, train_cfg=train_cfg)
+    batch = data.to_device(data.synthetic_batch(B=32, Tmax=128, n_mels=80, seed=rank), device)
+    n_frm = int(batch['mel_len'].sum())
+    n_tok = int(batch['x_len'].sum())
+    dur0 = batch['dur'].clone()
+
+    def one_step():
+        batch['dur'].copy_(dur0)              # the LengthRegulator clamps dur in place
+        return ts.step(batch)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = torch.tensor([dt, float(n_frm), float(n_tok)], device=device, dtype=torch.float64)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+        tot_frm, tot_tok = float(sm[1]), float(sm[2])
+    else:
+        tot_frm, tot_tok = float(n_frm), float(n_tok)
+    loss = float(out['loss'])
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = tot_frm * args.steps / dt
+        step_tflops = data.train_flops(tot_tok, tot_frm) / (dt / args.steps) / 1e12
+        roof = dominant_kernel_roofline(device)
+        roof['step'] = {'algorithmic_tflops': round(step_tflops, 2),
+                        'frac_of_f32_mfma_peak': round(step_tflops / (F32_MFMA_PEAK_TFLOPS * world), 4),
+                        'flop_per_valid_frame': 64.5e6}
+        line = {
+            'metric': 'mel_frames_per_sec_train_step', 'value': round(value, 1), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'LJSpeech singlespeaker.yaml ForwardTacotron train step, bs=32/GPU, Tx=128, '
+                                   'Tm=841, fp32 (BASELINE configs[1])',
+                       'global_batch': 32 * world, 'frames_per_step': tot_frm, 'parallelism': f'dp{world}'},
+            'per_gpu': round(value / world, 1), 'loss': round(loss, 5),
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(model_cfg, train_cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

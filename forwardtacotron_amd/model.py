@@ -145,28 +145,29 @@ class CBHG(nn.Module):
 
     # -- the K BatchNorms of the bank share flat storage so one kernel normalises the whole [B,T,K*C] buffer
     def _bank_flat(self):
+        """Returns flat [K*C] aliases (gamma, beta, running_mean, running_var) of the members' tensors.
+        Members already adjacent in memory (e.g. placed so by parallel.FlatParams, or by an earlier call)
+        are aliased as they are; otherwise they are re-homed into one fresh buffer.  load_state_dict copies
+        in place and keeps the aliasing; .to()/.cuda() break it and are repaired here."""
         bns = [m.bnorm for m in self.conv1d_bank]
-        C = bns[0].weight.numel()
-        f = self._flat
-        ok = f is not None and f[0].device == bns[0].weight.device
-        if ok:
-            for j, name in enumerate(('weight', 'bias', 'running_mean', 'running_var')):
-                for i in (0, len(bns) - 1):
-                    if getattr(bns[i], name).data_ptr() != f[j].data_ptr() + i * C * 4:
-                        ok = False
-        if not ok:
-            f = []
-            for name in ('weight', 'bias', 'running_mean', 'running_var'):
-                flat = torch.cat([getattr(b, name).detach().reshape(-1) for b in bns]).contiguous()
+        K, C = len(bns), bns[0].weight.numel()
+        out = []
+        for name in ('weight', 'bias', 'running_mean', 'running_var'):
+            ts = [getattr(b, name) for b in bns]
+            base = ts[0].data_ptr()
+            adjacent = all(ts[i].data_ptr() == base + 4 * i * C for i in range(1, K)) and \
+                ts[0].untyped_storage().nbytes() - 4 * ts[0].storage_offset() >= 4 * K * C
+            if not adjacent:
+                flat = torch.cat([t.detach().reshape(-1) for t in ts]).contiguous()
                 for i, b in enumerate(bns):
                     view = flat[i * C:(i + 1) * C]
                     if name in ('weight', 'bias'):
                         getattr(b, name).data = view
                     else:
                         b._buffers[name] = view
-                f.append(flat)
-            self._flat = f
-        return self._flat
+                ts = [getattr(b, name) for b in bns]
+            out.append(ts[0].detach().as_strided((K * C,), (1,)))
+        return out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         K = len(self.bank_kernels)

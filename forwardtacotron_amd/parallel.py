@@ -1,0 +1,153 @@
+"""Data-parallel plumbing for the train step (new work: the reference is single-device, train_forward.py:70).
+
+One process per GPU; gradients live in ONE flat fp32 buffer (parameters are views into a flat parameter
+buffer, laid out so that the tensors a fused kernel wants adjacent ARE adjacent).  The flat gradient is
+cut into buckets; a post-accumulate hook launches an asynchronous sum all-reduce (RCCL over xGMI for the
+"nccl" backend, gloo on CPU in tests) as soon as every gradient of a bucket has been produced, so the
+exchange overlaps the remaining backward (the 841-step recurrences dominate).
+Nothing here is model specific, which is what lets the CPU/gloo tests exercise the N>1 path.
+"""
+import re
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def _bank_group_key(name: str) -> Optional[Tuple[str, str, int]]:
+    """conv1d_bank.{i}.bnorm.{weight,bias} members must be contiguous (one BatchNorm kernel per bank)."""
+    m = re.match(r'^(.*conv1d_bank)\.(\d+)\.bnorm\.(weight|bias)$', name)
+    return (m.group(1), m.group(3), int(m.group(2))) if m else None
+
+
+class FlatParams:
+    """Re-homes every parameter of `module` into one flat buffer (p.data becomes a view) and gives each
+    parameter a .grad view into a flat gradient buffer.  Alignment: every tensor starts on a 16-byte
+    boundary unless it belongs to a contiguity group (bank BatchNorm weights), which is packed densely."""
+
+    def __init__(self, module: torch.nn.Module, group_key: Callable[[str], Optional[tuple]] = _bank_group_key):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        groups: Dict[tuple, List[Tuple[int, str, torch.nn.Parameter]]] = {}
+        rest = []
+        for n, p in named:
+            k = group_key(n)
+            if k is None:
+                rest.append((n, p))
+            else:
+                groups.setdefault(k[:2], []).append((k[2], n, p))
+        order: List[Tuple[str, torch.nn.Parameter, bool]] = []      # (name, param, dense-follow)
+        for key in sorted(groups):
+            members = sorted(groups[key], key=lambda t: t[0])
+            for j, (_, n, p) in enumerate(members):
+                order.append((n, p, j > 0))
+        for n, p in rest:
+            order.append((n, p, False))
+        self.names, self.params, self.offsets = [], [], []
+        off = 0
+        for n, p, dense in order:
+            if not dense:
+                off = (off + 3) // 4 * 4
+            self.names.append(n)
+            self.params.append(p)
+            self.offsets.append(off)
+            off += p.numel()
+        self.total = (off + 3) // 4 * 4
+        dev, dt = order[0][1].device, order[0][1].dtype
+        self.flat = torch.zeros(self.total, device=dev, dtype=dt)
+        self.grad = torch.zeros(self.total, device=dev, dtype=dt)
+        for p, o in zip(self.params, self.offsets):
+            self.flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+        self.attach()
+
+    def attach(self) -> None:
+        """(Re)points p.data / p.grad at the flat buffers (call again if something replaced them)."""
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def attached(self) -> bool:
+        p, o = self.params[-1], self.offsets[-1]
+        return (p.data_ptr() == self.flat.data_ptr() + 4 * o and p.grad is not None
+                and p.grad.data_ptr() == self.grad.data_ptr() + 4 * o)
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+
+class BucketedAllReduce:
+    """Sum all-reduce of a flat gradient buffer in buckets, overlapped with backward.
+
+    Buckets are contiguous ranges of the flat buffer filled in the order gradients become ready
+    (reverse registration order is a good prior: post_proj / postnet first).  `start()` arms the hooks'
+    counters for one backward; `finish()` waits (stream-level) for all launched collectives and launches
+    any bucket whose hooks never fired (unused parameters keep their zero gradient)."""
+
+    def __init__(self, flat: FlatParams, process_group=None, bucket_bytes: int = 24 << 20):
+        self.flat = flat
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # bucket boundaries over the flat layout, walking parameters from the END (first grads ready)
+        self.buckets: List[Tuple[int, int]] = []
+        self.param_bucket: List[int] = [0] * len(flat.params)
+        hi = flat.total
+        lo_idx = len(flat.params)
+        cur_members = []
+        limit = max(bucket_bytes // 4, 1)
+        for i in range(len(flat.params) - 1, -1, -1):
+            cur_members.append(i)
+            start = flat.offsets[i]
+            if hi - start >= limit or i == 0:
+                if i == 0:
+                    start = 0
+                bi = len(self.buckets)
+                self.buckets.append((start, hi))
+                for j in cur_members:
+                    self.param_bucket[j] = bi
+                cur_members = []
+                hi = start
+        self.bucket_size = [0] * len(self.buckets)
+        for j, b in enumerate(self.param_bucket):
+            self.bucket_size[b] += 1
+        self.pending = list(self.bucket_size)
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+        self.armed = False
+        if self.world > 1:
+            for j, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(j))
+
+    def _make_hook(self, j: int):
+        def hook(_p):
+            if not self.armed:
+                return
+            b = self.param_bucket[j]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: int) -> None:
+        if self.launched[b]:
+            return
+        lo, hi = self.buckets[b]
+        self.launched[b] = True
+        self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
+                                          async_op=True))
+
+    def start(self) -> None:
+        self.pending = list(self.bucket_size)
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+        self.armed = True
+
+    def finish(self) -> None:
+        """After backward(): the flat gradient holds the SUM over ranks (divide by world in the optimiser)."""
+        self.armed = False
+        if self.world <= 1:
+            return
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        for w in self.works:
+            w.wait()
+        self.works = []

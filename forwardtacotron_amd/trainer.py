@@ -1,0 +1,100 @@
+"""One optimisation step of ForwardTrainer.train_session (trainer/forward_trainer.py:69-99), MI355X-native.
+
+    loss = L1m(mel) + L1m(mel_post) + f_d*L1m(dur) + f_p*L1m(pitch) + f_e*L1m(energy)
+    zero_grad -> backward -> clip_grad_norm_(max_norm) -> Adam.step
+
+Forward, losses and backward are the HIP ops of forwardtacotron_amd.ops; clip + Adam run as two fused
+kernels over the flat parameter / gradient buffers (no per-tensor loop, no host sync); with a process
+group the flat gradient is sum-all-reduced in buckets overlapped with backward (RCCL over xGMI) and the
+1/world factor is folded into the clip coefficient.  BatchNorm statistics stay per rank (the reference has
+no SyncBN), every rank applies the identical Adam update.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from . import hip as H
+from . import ops
+from .parallel import BucketedAllReduce, FlatParams
+
+DEFAULT_TRAIN_CFG = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss_factor=0.1,
+                         pitch_zoneout=0.0, energy_zoneout=0.0, clip_grad_norm=1.0)
+
+
+class TrainStep:
+    def __init__(self, model: torch.nn.Module, lr: float, train_cfg: Optional[dict] = None,
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_bytes: int = 24 << 20):
+        self.model = model
+        self.lr = float(lr)
+        self.cfg = dict(DEFAULT_TRAIN_CFG)
+        if train_cfg:
+            self.cfg.update(train_cfg)
+        self.betas, self.eps = betas, eps
+        self.flat = FlatParams(model)
+        dev = self.flat.flat.device
+        if dev.type != 'cuda':
+            raise _lib.FtError('TrainStep needs the model on an MI355X (HIP) device')
+        self.exp_avg = torch.zeros_like(self.flat.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat)
+        self.opt_step = 0
+        self.coef = torch.zeros(2, device=dev, dtype=torch.float32)      # [clip coefficient, grad norm]
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.reducer = BucketedAllReduce(self.flat, process_group, bucket_bytes)
+
+    # -- state for checkpoints: same content as torch.optim.Adam's (exp_avg / exp_avg_sq / step), flat
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
+                'step': torch.tensor(self.opt_step), 'lr': torch.tensor(self.lr)}
+
+    def losses(self, pred: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], pitch_target, energy_target):
+        """forward_trainer.py:83-93"""
+        c = self.cfg
+        m1 = ops.masked_l1(pred['mel'], batch['mel'], batch['mel_len'])
+        m2 = ops.masked_l1(pred['mel_post'], batch['mel'], batch['mel_len'])
+        dl = ops.masked_l1(pred['dur'].unsqueeze(1), batch['dur'].unsqueeze(1), batch['x_len'])
+        pl = ops.masked_l1(pred['pitch'], pitch_target.unsqueeze(1), batch['x_len'])
+        el = ops.masked_l1(pred['energy'], energy_target.unsqueeze(1), batch['x_len'])
+        loss = m1 + m2 + c['dur_loss_factor'] * dl + c['pitch_loss_factor'] * pl + c['energy_loss_factor'] * el
+        return {'loss': loss, 'mel': m1, 'mel_post': m2, 'dur': dl, 'pitch': pl, 'energy': el}
+
+    def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """batch: device tensors with the ForwardCollator layout (utils/dataset.py:239-263).  Returns the
+        loss terms and the pre-clip gradient norm as device scalars (no host sync in here except the
+        LengthRegulator's output-size read, which the reference has too)."""
+        model = self.model
+        model.train()
+        if not self.flat.attached():
+            self.flat.attach()
+        c = self.cfg
+        pitch_target = batch['pitch'].detach().clone()
+        energy_target = batch['energy'].detach().clone()
+        if c['pitch_zoneout'] > 0 or c['energy_zoneout'] > 0:
+            batch = dict(batch)
+            dev = batch['x'].device
+            pm = (torch.rand(batch['x'].size()) > c['pitch_zoneout']).to(dev).float()
+            em = (torch.rand(batch['x'].size()) > c['energy_zoneout']).to(dev).float()
+            batch['pitch'] = batch['pitch'] * pm
+            batch['energy'] = batch['energy'] * em
+        pred = model(batch)
+        L = self.losses(pred, batch, pitch_target, energy_target)
+        self.flat.zero_grad()
+        self.reducer.start()
+        L['loss'].backward()
+        self.reducer.finish()
+        self.optimizer_step()
+        out = {k: v.detach() for k, v in L.items()}
+        out['grad_norm'] = self.coef[1]
+        return out
+
+    def optimizer_step(self) -> None:
+        f = self.flat
+        ws = H.workspace(_lib.query('ft_grad_norm_workspace'), f.flat.device)
+        max_norm = self.cfg.get('clip_grad_norm') or 0.0
+        _lib.call('ft_clip_grad_norm', f.grad.data_ptr(), f.total, float(max_norm), 1.0 / self.world,
+                  self.coef.data_ptr(), ws.data_ptr(), ws.numel(), H._stream())
+        self.opt_step += 1
+        _lib.call('ft_adam_step', f.flat.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
+                  self.exp_avg_sq.data_ptr(), f.total, self.lr, self.betas[0], self.betas[1], self.eps,
+                  self.opt_step, self.coef.data_ptr(), H._stream())

@@ -167,6 +167,17 @@ int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, co
 int ft_fill_padded(const float* raw, const long* lens, float* out, int B, int T, int C, float pad, void* stream);
 int ft_mask_rows(const float* src, const long* lens, float* dst, int B, int T, int C, void* stream);
 
+/* ---- clip_grad_norm_ + torch.optim.Adam (trainer/forward_trainer.py:95-99 ; train_forward.py:76) ------ */
+/* over FLAT fp32 buffers (all parameters back to back, 16-B aligned).  coef_and_norm[0] = pre_scale *
+ * min(1, max_norm/(norm+1e-6)), [1] = norm = pre_scale*||grads||_2 (pre_scale = 1/world_size when the buffer
+ * holds an all-reduced SUM); max_norm <= 0 disables clipping.  Stays on device: no host sync. */
+size_t ft_grad_norm_workspace(void);
+int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scale, float* coef_and_norm,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Adam, torch defaults semantics (no weight decay / amsgrad): g = grads*coef[0]; step counts from 1 */
+int ft_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                 float beta2, float eps, long step, const float* coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
