@@ -9,6 +9,12 @@ import os
 import re
 from typing import Dict, List, Tuple
 
+# torch must be imported BEFORE libfwdtaco_hip.so is dlopen'ed: PyTorch-ROCm bundles its own libamdhip64 /
+# libhsa-runtime64 (same SONAME as /opt/rocm's).  Loading ours first pulls in a second HIP runtime that owns
+# no device ("no ROCm-capable device is detected"); loading torch first makes both share one runtime, one
+# device context and the same streams.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libfwdtaco_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'fwdtaco_hip.h')

@@ -178,8 +178,10 @@ struct ChunkPlan {
 };
 ChunkPlan plan_chunks(long rows, int C) {
   int cb = ft_cdiv(C, 64);
-  long want = 2048 / (cb > 0 ? cb : 1);
-  if (want < 1) want = 1;
+  // enough blocks to fill the chip, few enough chunks that the per-channel ordered finalize stays short
+  long want = 1024 / (cb > 0 ? cb : 1);
+  if (want < 16) want = 16;
+  if (want > 64) want = 64;
   long maxc = (rows + 63) / 64;
   if (maxc < 1) maxc = 1;
   long n = want < maxc ? want : maxc;

@@ -47,23 +47,34 @@ int ft_device_info(int* cu_count, int* is_gfx950) {
 }
 
 // ------------------------------------------------------------------------------------------------
+static int check_tm(const char* what, int rows, int tm_B) {
+  if (tm_B > 0 && rows % tm_B != 0) {
+    ft_set_error("%s: rows (%d) not a multiple of the time-major batch (%d)", what, rows, tm_B);
+    return FT_ERR_ARG;
+  }
+  return FT_OK;
+}
+
 int ft_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int rows, int in_f,
-                  int out_f, int relu, int accumulate, void* stream) {
+                  int out_f, int relu, int accumulate, int x_tm_B, int y_tm_B, void* stream) {
+  if (check_tm("linear_fwd", rows, x_tm_B) || check_tm("linear_fwd", rows, y_tm_B)) return FT_ERR_ARG;
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   FtGemmTask& t = b.t[0];
   t.A = x; t.B = w; t.C = y; t.bias = bias;
   t.lda = ldx; t.ldb = in_f; t.ldc = ldy; t.b_tap_stride = 0;
   t.M = rows; t.N = out_f; t.K = in_f; t.taps = 1;
-  t.amap = ft_rowmap_identity(rows);
+  t.amap = ft_rowmap_layout(rows, x_tm_B);
+  t.cmap = ft_rowmap_layout(rows, y_tm_B);
   t.relu = relu; t.accumulate = accumulate;
   return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
 }
 
 int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
                         float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
-                        void* stream) {
+                        int x_tm_B, int y_tm_B, void* stream) {
   FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_multi_fwd: ntasks %d out of range", ntasks);
+  if (check_tm("linear_multi_fwd", rows, x_tm_B) || check_tm("linear_multi_fwd", rows, y_tm_B)) return FT_ERR_ARG;
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   for (int i = 0; i < ntasks; ++i) {
@@ -71,55 +82,63 @@ int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const
     t.A = x; t.B = w[i]; t.C = y + col_offset[i]; t.bias = bias ? bias[i] : nullptr;
     t.lda = ldx; t.ldb = in_f; t.ldc = ldy;
     t.M = rows; t.N = out_f[i]; t.K = in_f; t.taps = 1;
-    t.amap = ft_rowmap_identity(rows);
+    t.amap = ft_rowmap_layout(rows, x_tm_B);
+    t.cmap = ft_rowmap_layout(rows, y_tm_B);
     t.relu = relu;
   }
   return ft_launch_gemm_rows(&b, ntasks, false, (hipStream_t)stream);
 }
 
 int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, long lddx, int rows, int in_f,
-                       int out_f, int accumulate, void* stream) {
+                       int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream) {
+  if (check_tm("linear_bwd_data", rows, dy_tm_B) || check_tm("linear_bwd_data", rows, dx_tm_B)) return FT_ERR_ARG;
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   FtGemmTask& t = b.t[0];
   t.A = dy; t.B = w; t.C = dx;
   t.lda = lddy; t.ldb = in_f; t.ldc = lddx;
   t.M = rows; t.N = in_f; t.K = out_f; t.taps = 1;
-  t.amap = ft_rowmap_identity(rows);
+  t.amap = ft_rowmap_layout(rows, dy_tm_B);
+  t.cmap = ft_rowmap_layout(rows, dx_tm_B);
   t.accumulate = accumulate;
   return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
 }
 
 static FtGemmTNTask linear_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int rows,
-                                   int in_f, int out_f, int B, int T, int x_shift, int accumulate) {
+                                   int in_f, int out_f, int B, int T, int x_shift, int accumulate, int dy_tm,
+                                   int x_tm) {
   FtGemmTNTask t;
   memset(&t, 0, sizeof(t));
   t.A = dy; t.B = x; t.dst = dw;
   t.lda = lddy; t.ldb = ldx;
   t.ldm = in_f; t.ldn = 1; t.ldj = 0;
   t.M = out_f; t.N = in_f; t.R = rows; t.taps = 1;
-  t.amap = ft_rowmap_identity(rows);
-  if (x_shift == 0) {
+  if (x_shift == 0 && !dy_tm && !x_tm) {
+    t.amap = ft_rowmap_identity(rows);
     t.bmap = ft_rowmap_identity(rows);
-  } else {
-    FtRowMap m = {T, T, T, x_shift, 0};
-    t.bmap = m;
+  } else {          // both maps share the logical (b, t) decomposition with Tlog = T
+    int Tl = T > 0 ? T : 1;
+    FtRowMap am = {Tl, dy_tm ? 1 : Tl, dy_tm ? B : 1, Tl, 0, 0};
+    FtRowMap bm = {Tl, x_tm ? 1 : Tl, x_tm ? B : 1, Tl, x_shift, 0};
+    t.amap = am;
+    t.bmap = bm;
   }
-  (void)B;
   t.accumulate = accumulate;
   return t;
 }
 
 size_t ft_linear_bwd_weight_workspace(int rows, int in_f, int out_f) {
-  FtGemmTNTask t = linear_bw_task(nullptr, out_f, nullptr, in_f, nullptr, rows, in_f, out_f, 1, rows, 0, 0);
+  FtGemmTNTask t = linear_bw_task(nullptr, out_f, nullptr, in_f, nullptr, rows, in_f, out_f, 1, rows, 0, 0, 0, 0);
   return ft_gemm_tn_workspace_floats(t) * sizeof(float);
 }
 
 int ft_linear_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int rows, int in_f,
-                         int out_f, int B, int T, int x_shift, int accumulate, void* workspace,
-                         size_t workspace_bytes, void* stream) {
-  FT_REQUIRE(x_shift == 0 || (long)B * T == rows, "linear_bwd_weight: rows != B*T with a row shift");
-  FtGemmTNTask t = linear_bw_task(dy, lddy, x, ldx, dw, rows, in_f, out_f, B, T, x_shift, accumulate);
+                         int out_f, int B, int T, int x_shift, int accumulate, int dy_time_major, int x_time_major,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE((x_shift == 0 && !dy_time_major && !x_time_major) || (long)B * T == rows,
+             "linear_bwd_weight: rows != B*T with a row shift / time-major operand");
+  FtGemmTNTask t = linear_bw_task(dy, lddy, x, ldx, dw, rows, in_f, out_f, B, T, x_shift, accumulate, dy_time_major,
+                                  x_time_major);
   return ft_launch_gemm_tn(t, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
 }
 
@@ -131,7 +150,7 @@ static void conv_fwd_task(FtGemmTask& t, const float* x, long ldx, const float* 
   t.A = x; t.B = wp; t.C = y;
   t.lda = ldx; t.ldb = Cin; t.ldc = ldy; t.b_tap_stride = (long)Cout * Cin;
   t.M = B * Tout; t.N = Cout; t.K = Cin; t.taps = k;
-  FtRowMap m = {Tout, T, T, -(k / 2), 1};
+  FtRowMap m = {Tout > 0 ? Tout : 1, T, 1, T, -(k / 2), 1};
   t.amap = m;
   t.relu = relu;
 }
@@ -175,7 +194,7 @@ int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, l
   t.A = dy; t.B = wp; t.C = dx;
   t.lda = lddy; t.ldb = Cin; t.ldc = lddx; t.b_tap_stride = (long)Cout * Cin;
   t.M = B * T; t.N = Cin; t.K = Cout; t.taps = k;
-  FtRowMap m = {T, Tbuf, Tvalid, k / 2, -1};     // dy row = t - tap + pad
+  FtRowMap m = {T > 0 ? T : 1, Tbuf, 1, Tvalid, k / 2, -1};     // dy row = t - tap + pad
   t.amap = m;
   t.accumulate = accumulate;
   return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
@@ -189,8 +208,9 @@ static FtGemmTNTask conv_bw_task(const float* dy, long lddy, const float* x, lon
   t.lda = lddy; t.ldb = ldx;
   t.ldm = (long)Cin * k; t.ldn = k; t.ldj = 1;       // torch layout [Cout][Cin][k]
   t.M = Cout; t.N = Cin; t.R = B * Tvalid; t.taps = k;
-  FtRowMap am = {Tvalid, Tbuf, Tvalid, 0, 0};
-  FtRowMap bm = {Tvalid, T, T, -(k / 2), 1};
+  int Tl = Tvalid > 0 ? Tvalid : 1;
+  FtRowMap am = {Tl, Tbuf, 1, Tvalid, 0, 0};
+  FtRowMap bm = {Tl, T, 1, T, -(k / 2), 1};
   t.amap = am;
   t.bmap = bm;
   return t;

@@ -50,20 +50,14 @@ __global__ void ft_embedding_fwd_kernel(const long* __restrict__ idx, const floa
   out[i] = w[v * C + c];
 }
 
-// dW[v][c] = sum over rows with idx==v of dout[row][c]  (row order -> reproducible)
-__global__ __launch_bounds__(256) void ft_embedding_bwd_kernel(const long* __restrict__ idx,
-                                                               const float* __restrict__ dout,
-                                                               float* __restrict__ dw, long rows, int C) {
-  __shared__ float red[4][64];
-  const int v = blockIdx.x;
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + cl;
-  float acc = 0.f;
-  for (long r = rl; r < rows; r += 4)
-    if (idx[r] == v && c < C) acc += dout[r * C + c];
-  red[rl][cl] = acc;
-  __syncthreads();
-  if (rl == 0 && c < C) dw[(long)v * C + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+// onehot[row][v] = (idx[row] == v): the embedding weight gradient is then onehot^T * dout, one TN MFMA GEMM
+// (ordered split reduction -> reproducible), shared by every embedding table fed by the same ids
+__global__ void ft_onehot_kernel(const long* __restrict__ idx, float* __restrict__ out, long rows, int V) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * V) return;
+  long r = i / V;
+  int v = (int)(i - r * V);
+  out[i] = idx[r] == v ? 1.f : 0.f;
 }
 
 // ---- highway (common_layers.py:35-40): x12 = [W1 x + b1 | W2 x + b2] -------------------------------
@@ -130,20 +124,21 @@ __global__ void ft_cond_add_kernel(const float* __restrict__ x, const float* __r
                                    const float* __restrict__ energy, const float* __restrict__ wp,
                                    const float* __restrict__ bp, const float* __restrict__ we,
                                    const float* __restrict__ be, float sp, float se, float* __restrict__ out, int B,
-                                   int T, int C) {
+                                   int T, int C, int x_time_major) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)B * T * C;
   if (i >= total) return;
   int c = (int)(i % C);
   long row = i / C;
   int t = (int)(row % T);
+  const float xv = x_time_major ? x[((long)t * B + (row / T)) * C + c] : x[i];
   const float* p = pitch + row;
   const float* e = energy + row;
   float pm = t > 0 ? p[-1] : 0.f, pc = p[0], pn = t + 1 < T ? p[1] : 0.f;
   float em = t > 0 ? e[-1] : 0.f, ec = e[0], en = t + 1 < T ? e[1] : 0.f;
   float a = bp[c] + wp[c * 3 + 0] * pm + wp[c * 3 + 1] * pc + wp[c * 3 + 2] * pn;
   float b = be[c] + we[c * 3 + 0] * em + we[c * 3 + 1] * ec + we[c * 3 + 2] * en;
-  out[i] = x[i] + sp * a + se * b;
+  out[i] = xv + sp * a + se * b;
 }
 // P[row][0..7] = [p[t-1], p[t], p[t+1], 1, e[t-1], e[t], e[t+1], 1]  (weight grads = dy^T P via the TN GEMM)
 __global__ void ft_cond_taps_kernel(const float* __restrict__ pitch, const float* __restrict__ energy,
@@ -214,19 +209,29 @@ __global__ __launch_bounds__(256) void ft_masked_l1_partial_kernel(const float* 
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 // loss = sum(partial) / (C * sum_b min(len_b, T)) ; also stores 1/denominator for the backward
-__global__ void ft_masked_l1_finalize_kernel(const double* __restrict__ partial, int nblocks,
-                                             const long* __restrict__ lens, int B, int C, int T,
-                                             float* __restrict__ loss, float* __restrict__ inv_denom) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0;
-  for (int i = 0; i < nblocks; ++i) s += partial[i];
-  double n = 0.0;
-  for (int b = 0; b < B; ++b) {
+__global__ __launch_bounds__(256) void ft_masked_l1_finalize_kernel(const double* __restrict__ partial, int nblocks,
+                                                                    const long* __restrict__ lens, int B, int C,
+                                                                    int T, float* __restrict__ loss,
+                                                                    float* __restrict__ inv_denom) {
+  __shared__ double red[2][4];
+  double s = 0.0, n = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+  for (int b = threadIdx.x; b < B; b += 256) {
     long l = lens[b];
     if (l < 0) l = 0;
     if (l > T) l = T;
     n += (double)l;
   }
+  s = ft_wave_sum_d(s);
+  n = ft_wave_sum_d(n);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  n = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   n *= (double)C;
   *loss = (float)(s / n);
   *inv_denom = (float)(1.0 / n);
@@ -285,12 +290,12 @@ int ft_embedding_fwd(const long* idx, const float* w, float* out, long rows, int
   return ft_check_launch("embedding_fwd");
 }
 
-int ft_embedding_bwd(const long* idx, const float* dout, float* dw, long rows, int C, int V, void* stream) {
-  FT_REQUIRE(rows >= 0 && C >= 0 && V > 0, "embedding_bwd: bad dims");
-  if (C == 0) return FT_OK;
-  hipLaunchKernelGGL(ft_embedding_bwd_kernel, dim3(V, ft_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, idx, dout,
-                     dw, rows, C);
-  return ft_check_launch("embedding_bwd");
+int ft_onehot(const long* idx, float* out, long rows, int V, void* stream) {
+  FT_REQUIRE(rows >= 0 && V > 0, "onehot: bad dims");
+  if (rows == 0) return FT_OK;
+  hipLaunchKernelGGL(ft_onehot_kernel, dim3(ft_cdiv(rows * V, 256)), dim3(256), 0, (hipStream_t)stream, idx, out, rows,
+                     V);
+  return ft_check_launch("onehot");
 }
 
 int ft_highway_gate_fwd(const float* x12, const float* x, float* out, long rows, int C, void* stream) {
@@ -326,11 +331,12 @@ int ft_maxpool2_bwd(const float* dout, const float* x, float* dx, int B, int T, 
 
 int ft_cond_add_fwd(const float* x, const float* pitch, const float* energy, const float* w_pitch,
                     const float* b_pitch, const float* w_energy, const float* b_energy, float pitch_strength,
-                    float energy_strength, float* out, int B, int T, int C, void* stream) {
+                    float energy_strength, float* out, int B, int T, int C, int x_time_major, void* stream) {
   long total = (long)B * T * C;
   if (total <= 0) return FT_OK;
   hipLaunchKernelGGL(ft_cond_add_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, pitch,
-                     energy, w_pitch, b_pitch, w_energy, b_energy, pitch_strength, energy_strength, out, B, T, C);
+                     energy, w_pitch, b_pitch, w_energy, b_energy, pitch_strength, energy_strength, out, B, T, C,
+                     x_time_major);
   return ft_check_launch("cond_add_fwd");
 }
 
@@ -370,7 +376,7 @@ int ft_masked_l1_fwd(const float* x, const float* target, const long* lens, floa
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(ft_masked_l1_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, target, lens, B, C, T,
                      (double*)workspace);
-  hipLaunchKernelGGL(ft_masked_l1_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ft_masked_l1_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                      (const double*)workspace, nb, lens, B, C, T, loss, inv_denom);
   return ft_check_launch("masked_l1_fwd");
 }

@@ -2,18 +2,28 @@
 #pragma once
 #include "ft_common.h"
 
-// logical row r = (b, t), t in [0,Tlog):  physical row = b*Tstride + (t+shift),
-// valid iff 0 <= t+shift < Tvalid ; invalid rows read as zeros.  shift = shift0 + tap*shift_step.
+// logical row r = (b, t), b = r / Tlog, t = r % Tlog:
+//   physical row = b*bstride + (t+shift)*tstride, valid iff 0 <= t+shift < Tvalid ; invalid rows read as zeros.
+//   shift = shift0 + tap*shift_step.
+// batch-major [B,Tbuf,C]: bstride = Tbuf, tstride = 1 ; time-major [T,B,C]: bstride = 1, tstride = B.
 struct FtRowMap {
-  int Tlog, Tstride, Tvalid, shift0, shift_step;
+  int Tlog, bstride, tstride, Tvalid, shift0, shift_step;
 };
 
 static inline FtRowMap ft_rowmap_identity(int rows) {
-  FtRowMap m = {rows > 0 ? rows : 1, rows > 0 ? rows : 1, rows > 0 ? rows : 1, 0, 0};
+  int n = rows > 0 ? rows : 1;
+  FtRowMap m = {n, 0, 1, n, 0, 0};
+  return m;
+}
+// rows = B*T logical (b,t) positions stored time-major ([T,B,C]) when tm_B > 0, else plain row-major
+static inline FtRowMap ft_rowmap_layout(int rows, int tm_B) {
+  if (tm_B <= 0) return ft_rowmap_identity(rows);
+  int T = rows / tm_B;
+  FtRowMap m = {T > 0 ? T : 1, 1, tm_B, T, 0, 0};
   return m;
 }
 
-// C[M,N] (+)= sum_{tap} Amap_tap(A)[M,K] * B_tap   (+bias, relu)
+// C[cmap(M),N] (+)= sum_{tap} Amap_tap(A)[M,K] * B_tap   (+bias, relu, affine)
 //   B_NCONTIG = false: B_tap[n][k] at B + tap*b_tap_stride + n*ldb + k   ("NT")
 //   B_NCONTIG = true : B_tap[k][n] at B + tap*b_tap_stride + k*ldb + n   ("NN")
 struct FtGemmTask {
@@ -26,6 +36,7 @@ struct FtGemmTask {
   long lda, ldb, ldc, b_tap_stride;
   int M, N, K, taps;
   FtRowMap amap;
+  FtRowMap cmap;        // output row permutation (Tlog/bstride/tstride only); identity by default
   int relu, accumulate, a_vec, b_vec;
 };
 #define FT_MAX_TASKS 16

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
     a_ok[p] = m < T.M;
     int b = m / T.amap.Tlog;
     a_t[p] = m - b * T.amap.Tlog;
-    a_base[p] = (long)b * T.amap.Tstride;
+    a_base[p] = (long)b * T.amap.bstride;
   }
   const int kch = (T.K + BK - 1) / BK;
   const int nch = T.taps * kch;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
     for (int p = 0; p < PA; ++p) {
       int ts = a_t[p] + shift;
       bool ok = a_ok[p] && ts >= 0 && ts < T.amap.Tvalid;
-      const float* ptr = T.A + (a_base[p] + ts) * T.lda + k;
+      const float* ptr = T.A + (a_base[p] + (long)ts * T.amap.tstride) * T.lda + k;
       ra[p] = ld4(ptr, ok ? T.K - k : 0, T.a_vec);
     }
     const float* Bj = T.B + (long)j * T.b_tap_stride;
@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (row >= T.M) continue;
-        float* cp = T.C + (long)row * T.ldc + col;
+        const int cb = row / T.cmap.Tlog;
+        const long crow = (long)cb * T.cmap.bstride + (long)(row - cb * T.cmap.Tlog) * T.cmap.tstride;
+        float* cp = T.C + crow * T.ldc + col;
         float v = acc[i][j][e] + bv;
         if (T.relu) v = fmaxf(v, 0.f);
         if (T.scale) v = v * sc + sh;
@@ -212,7 +214,8 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       int ts = r - b * T.amap.Tlog + ashift;
       bool ok = r < r_end && ts >= 0 && ts < T.amap.Tvalid;
       int m = m0 + 4 * aq;
-      ra[p] = ld4(T.A + ((long)b * T.amap.Tstride + ts) * T.lda + m, ok ? T.M - m : 0, T.a_vec);
+      ra[p] = ld4(T.A + ((long)b * T.amap.bstride + (long)ts * T.amap.tstride) * T.lda + m, ok ? T.M - m : 0,
+                  T.a_vec);
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       int ts = r - b * T.bmap.Tlog + bshift;
       bool ok = r < r_end && ts >= 0 && ts < T.bmap.Tvalid;
       int n = n0 + 4 * bq;
-      rb[p] = ld4(T.B + ((long)b * T.bmap.Tstride + ts) * T.ldb + n, ok ? T.N - n : 0, T.b_vec);
+      rb[p] = ld4(T.B + ((long)b * T.bmap.bstride + (long)ts * T.bmap.tstride) * T.ldb + n, ok ? T.N - n : 0,
+                  T.b_vec);
     }
   };
   auto store_stage = [&]() {
@@ -338,6 +342,7 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
     FtGemmTask& t = batch->t[i];
     FT_REQUIRE(t.M >= 0 && t.N >= 0 && t.K >= 0 && t.taps >= 1, "gemm_rows: bad dims");
     FT_REQUIRE(t.amap.Tlog > 0, "gemm_rows: bad row map");
+    if (t.cmap.Tlog <= 0) t.cmap = ft_rowmap_identity(t.M);     // tasks built with memset(0): identity output
     t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0);
     t.b_vec = (t.ldb % 4 == 0) && (t.b_tap_stride % 4 == 0) && (((uintptr_t)t.B) % 16 == 0);
     if (t.M > maxM) maxM = t.M;

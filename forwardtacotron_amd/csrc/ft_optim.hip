@@ -27,11 +27,17 @@ __global__ __launch_bounds__(256) void ft_sumsq_partial_kernel(const float* __re
 }
 
 // norm = sqrt(sum)*pre_scale ; coef = pre_scale * min(1, max_norm / (norm + 1e-6))   (max_norm <= 0: no clipping)
-__global__ void ft_clip_coef_kernel(const double* __restrict__ partial, int nblocks, float max_norm, float pre_scale,
-                                    float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void ft_clip_coef_kernel(const double* __restrict__ partial, int nblocks,
+                                                           float max_norm, float pre_scale,
+                                                           float* __restrict__ out) {
+  __shared__ double red[4];
   double s = 0.0;
-  for (int i = 0; i < nblocks; ++i) s += partial[i];
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];   // fixed assignment -> reproducible
+  s = ft_wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  s = red[0] + red[1] + red[2] + red[3];
   float norm = (float)sqrt(s) * pre_scale;
   float c = 1.0f;
   if (max_norm > 0.f) {
@@ -95,7 +101,7 @@ int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scal
   if (nb < 1) nb = 1;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ft_sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grads, n, (double*)workspace);
-  hipLaunchKernelGGL(ft_clip_coef_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nb, max_norm, pre_scale,
+  hipLaunchKernelGGL(ft_clip_coef_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, max_norm, pre_scale,
                      coef_and_norm);
   return ft_check_launch("clip_grad_norm");
 }

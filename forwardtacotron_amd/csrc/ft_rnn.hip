@@ -2,12 +2,20 @@
 // (models/common_layers.py:89,123 ; models/forward_tacotron.py:24,96-99,147-152).
 //
 // The input projections x*W_ih^T (+b_ih) are hoisted into one big MFMA GEMM (ft_linear_multi_fwd); what is
-// left per timestep is h[B,H] * W_hh^T[H,G*H] plus the cell math.  Version 1 of the recurrence issues ONE
-// launch per timestep covering both directions: a workgroup owns 32 batch rows x U=8 hidden units (all G
-// gates of those units -> 32 MFMA columns), the K=H contraction is split across the waves of the block
-// (each wave a strided set of 8-wide k-octets, operands loaded straight from L2 as 16-B lanes using the
-// "any K order, as long as A and B agree" freedom of the MFMA), partial 32x32 tiles are reduced through
-// LDS and 256 threads finish the cell update.  Kernel boundaries provide the step-to-step dependency.
+// left per timestep is h[B,H] * W_hh^T[H,G*H] plus the cell math.  The recurrence issues ONE launch per
+// timestep covering both directions; the kernel boundary is the step-to-step dependency.
+//
+// Per step the chip has to move W_hh (4 MB per direction for the 512-wide LSTM) plus the recurrent operand
+// through the per-CU L1 path, so the decomposition minimises BYTES PER CU rather than MFMA count:
+//   forward : workgroup = MT*16 batch rows x 16 gate rows (UB units, all G gates)  -> 256 workgroups
+//             for the LSTM, 96 KB of operands each; K = H split over the NW waves of the workgroup
+//   backward: workgroup = 16 batch rows x 16 hidden units, K = G*H split over NW waves (the 2048-wide
+//             d(gates) row block is the expensive operand, so the batch is split, not the K range)
+// Each wave prefetches its whole K slice into registers as 16-B lanes (f32 16x16x4 MFMA: lane (i,q) holds
+// row i, k = 16c+4q..+3 -- any K order is legal as long as A and B agree), then runs the MFMA chain;
+// per-wave partial 16x16 tiles are reduced through LDS and the same workgroup finishes the cell update.
+// The cell-update operands (x projection, biases, previous state, saved gates) are requested BEFORE the
+// matmul so their HBM latency hides under it.
 //
 // Time indexing (L_b = lens[b] for the packed LSTM, T otherwise); s = launch index:
 //   forward pass : t = s (dir 0) | L_b-1-s (dir 1) ;  h_prev at t-1 | t+1           ; active iff s < L_b
@@ -16,8 +24,8 @@
 
 namespace {
 
-constexpr int U = 8;        // hidden units per block in the forward step
-constexpr int RLD = 40;     // LDS row stride of the 32x32 partial tiles (conflict-free 8-wide reads)
+constexpr int RLD = 20;     // LDS row stride of the 16x16 partial tiles
+constexpr int GCH = 8;      // K groups (16 k each) prefetched per chunk
 
 __device__ __forceinline__ float4 ld4g(const float* p, int remaining, bool vec) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -32,19 +40,64 @@ __device__ __forceinline__ float4 ld4g(const float* p, int remaining, bool vec) 
   return v;
 }
 
-__device__ __forceinline__ void mfma4(const float4& a, const float4& b, f32x16& acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+__device__ __forceinline__ void mfma4(const float4& a, const float4& b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
 }
 
-// store this wave's 32x32 partial (lane: column l31, rows (e&3)+8*(e>>2)+4*half)
-__device__ __forceinline__ void store_partial(float* red, int wave, int lane, const f32x16& acc) {
-  const int half = lane >> 5, l31 = lane & 31;
-  float* r = red + wave * 32 * RLD;
+// acc[m] (+)= A_m[16 x K] * B[16 x K]^T over this wave's K groups [g0, g1); arow[m]/brow are the lane's
+// row pointers (row = lane&15), K contiguous.  Whole chunks of GCH groups are loaded before the MFMA chain.
+// FAST (K % 16 == 0, 16-B aligned rows): every load is an unconditional 16-B lane load -- callers clamp the
+// row pointer of an invalid lane to a valid row instead of predicating (row i of the product depends only on
+// A row i, column j only on B row j, and the invalid ones are never consumed), so the loop is branch-free
+// apart from the wave-uniform group-count test.  The generic path predicates every element (odd sizes).
+template <int MT, bool FAST>
+__device__ __forceinline__ void wave_matmul(const float* const (&arow)[MT], const bool (&aok)[MT], const float* brow,
+                                            bool bok, int K, int g0, int g1, int q, bool vec, f32x4 (&acc)[MT]) {
+  for (int gb = g0; gb < g1; gb += GCH) {
+    float4 av[MT][GCH], bv[GCH];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) r[((e & 3) + 8 * (e >> 2) + 4 * half) * RLD + l31] = acc[e];
+    for (int c = 0; c < GCH; ++c) {
+      const int k = 16 * (gb + c) + 4 * q;
+      if (FAST) {
+        if (gb + c < g1) {       // wave-uniform
+          bv[c] = *reinterpret_cast<const float4*>(brow + k);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[m][c] = *reinterpret_cast<const float4*>(arow[m] + k);
+        }
+      } else {
+        const bool in = (gb + c) < g1;
+        bv[c] = ld4g(brow + k, (in && bok) ? K - k : 0, vec);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m][c] = ld4g(arow[m] + k, (in && aok[m]) ? K - k : 0, vec);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < GCH; ++c) {
+      if (gb + c < g1) {        // wave-uniform: skip the MFMAs of groups beyond this wave's slice
+#pragma unroll
+        for (int m = 0; m < MT; ++m) mfma4(av[m][c], bv[c], acc[m]);
+      }
+    }
+  }
+}
+
+// partial tile store: lane holds column lane&15, rows (lane>>4)*4 + e
+template <int MT>
+__device__ __forceinline__ void store_partials(float* red, int wave, int lane, const f32x4 (&acc)[MT]) {
+  float* r = red + wave * (MT * 16 * RLD);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[(m * 16 + (lane >> 4) * 4 + e) * RLD + (lane & 15)] = acc[m][e];
+}
+
+__device__ __forceinline__ int clamp_len(const long* lens, int b, int T) {
+  if (!lens) return T;
+  long l = lens[b];
+  return l < 0 ? 0 : (l > T ? T : (int)l);
 }
 
 struct RnnFwdArgs {
@@ -58,88 +111,100 @@ struct RnnFwdArgs {
   int B, T, H, ND, s, vec;
 };
 
-template <int G, int NW>
+// workgroup: MT*16 batch rows x (UB = 16/G units, all G gates)
+template <int G, int NW, int MT, bool FAST>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_step_kernel(RnnFwdArgs a) {
-  __shared__ float red[NW * 32 * RLD];
+  constexpr int UB = 16 / G;
+  __shared__ float red[NW * MT * 16 * RLD];
   const int d = blockIdx.z;
-  const int u0 = blockIdx.x * U;
-  const int b0 = blockIdx.y * 32;
+  const int u0 = blockIdx.x * UB;
+  const int b0 = blockIdx.y * (MT * 16);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int half = lane >> 5, l31 = lane & 31;
+  const int q = lane >> 4, l15 = lane & 15;
   const int H = a.H, T = a.T, s = a.s;
   const long ldo = (long)a.ND * H;
 
-  // ---- A row (batch item) of this lane
-  const int bA = b0 + l31;
-  int LA = T;
-  if (bA < a.B && a.lens) {
-    long l = a.lens[bA];
-    LA = l < 0 ? 0 : (l > T ? T : (int)l);
-  }
-  const bool actA = bA < a.B && s < LA && s > 0;
-  const int tprevA = d == 0 ? s - 1 : LA - s;          // (t-1) | (t+1) with t = LA-1-s
-  const float* arow = a.out + ((long)bA * T + tprevA) * ldo + (long)d * H;
-  // ---- B column (gate row) of this lane
-  const int gj = l31 / U, ul = l31 - gj * U;
-  const bool okB = gj < G && (u0 + ul) < H;
-  const float* brow = a.whh[d] + ((long)gj * H + u0 + ul) * H;
-
-  f32x16 acc;
+  // ---- cell-update operands of this thread (requested now, consumed after the matmul)
+  const int ci = tid / UB, cu = tid - ci * UB;
+  const int cb = b0 + ci, cun = u0 + cu;
+  bool cact = tid < MT * 16 * UB && cb < a.B && cun < H;
+  int ct = 0;
+  float xg[G], bg[G], prev = 0.f;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const int noct = (H + 7) / 8;
-  if (s > 0) {
-
-    for (int c = wave; c < noct; c += NW) {
-      const int k = 8 * c + 4 * half;
-      float4 av = ld4g(arow + k, actA ? H - k : 0, a.vec);
-      float4 bv = ld4g(brow + k, okB ? H - k : 0, a.vec);
-      mfma4(av, bv, acc);
+  for (int g = 0; g < G; ++g) xg[g] = bg[g] = 0.f;
+  if (cact) {
+    const int L = clamp_len(a.lens, cb, T);
+    cact = s < L;
+    if (cact) {
+      ct = d == 0 ? s : L - 1 - s;
+      const int tprev = d == 0 ? ct - 1 : ct + 1;
+      const float* xr = a.xp + ((long)ct * a.B + cb) * ((long)a.ND * G * H) + (long)d * G * H + cun;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        xg[g] = xr[(long)g * H];
+        bg[g] = a.bhh[d][g * H + cun];
+      }
+      if (s > 0) {
+        const long op = ((long)tprev * a.B + cb) * ldo + (long)d * H + cun;
+        prev = G == 3 ? a.out[op] : a.cst[op];
+      }
     }
   }
-  store_partial(red, wave, lane, acc);
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[m][e] = 0.f;
+
+  if (s > 0) {
+    const float* arow[MT];
+    bool aok[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int bA = b0 + m * 16 + l15;
+      const int LA = bA < a.B ? clamp_len(a.lens, bA, T) : 0;
+      aok[m] = bA < a.B && s < LA;
+      const int tprev = d == 0 ? s - 1 : LA - s;        // (t-1) | (t+1) with t = LA-1-s
+      const long row = aok[m] ? (long)tprev * a.B + bA : 0;   // invalid lanes read row 0 (never consumed)
+      arow[m] = a.out + row * ldo + (long)d * H;
+    }
+    const int gj = l15 / UB, ul = l15 - gj * UB;
+    const bool bok = gj < G && (u0 + ul) < H;
+    const float* brow = a.whh[d] + (bok ? ((long)gj * H + u0 + ul) * H : 0);
+    const int ngroups = (H + 15) / 16;
+    const int gpw = (ngroups + NW - 1) / NW;
+    const int g0 = wave * gpw, g1 = min(ngroups, g0 + gpw);
+    wave_matmul<MT, FAST>(arow, aok, brow, bok, H, g0, g1, q, a.vec, acc);
+  }
+  store_partials<MT>(red, wave, lane, acc);
   __syncthreads();
 
-  if (tid < 32 * U) {
-    const int i = tid / U, uu = tid - i * U;
-    const int b = b0 + i, u = u0 + uu;
-    if (b >= a.B || u >= H) return;
-    int L = T;
-    if (a.lens) {
-      long l = a.lens[b];
-      L = l < 0 ? 0 : (l > T ? T : (int)l);
-    }
-    if (s >= L) return;
-    const int t = d == 0 ? s : L - 1 - s;
-    const int tprev = d == 0 ? t - 1 : t + 1;
+  if (cact) {
     float hp[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) v += red[w * 32 * RLD + i * RLD + g * U + uu];
-      hp[g] = v + a.bhh[d][g * H + u];
+      for (int w = 0; w < NW; ++w) v += red[w * (MT * 16 * RLD) + ci * RLD + g * UB + cu];
+      hp[g] = v + bg[g];
     }
-    const float* xr = a.xp + ((long)b * T + t) * ((long)a.ND * G * H) + (long)d * G * H + u;
-    const long o = ((long)b * T + t) * ldo + (long)d * H + u;
-    const long op = ((long)b * T + tprev) * ldo + (long)d * H + u;
-    float* gs = a.gates ? a.gates + (((long)b * T + t) * a.ND + d) * 4 * H + u : nullptr;
+    const long o = ((long)ct * a.B + cb) * ldo + (long)d * H + cun;
+    float* gs = a.gates ? a.gates + (((long)ct * a.B + cb) * a.ND + d) * 4 * H + cun : nullptr;
     if (G == 3) {
-      float r = ft_sigmoid(xr[0] + hp[0]);
-      float z = ft_sigmoid(xr[H] + hp[1]);
-      float n = ft_tanh(xr[2 * H] + r * hp[2]);
-      float hprev = s > 0 ? a.out[op] : 0.f;
-      a.out[o] = (1.f - z) * n + z * hprev;
+      float r = ft_sigmoid(xg[0] + hp[0]);
+      float z = ft_sigmoid(xg[1] + hp[1]);
+      float n = ft_tanh(xg[2] + r * hp[2]);
+      a.out[o] = (1.f - z) * n + z * prev;
       if (gs) {
         gs[0] = r; gs[H] = z; gs[2 * H] = n; gs[3 * H] = hp[2];
       }
     } else {
-      float ig = ft_sigmoid(xr[0] + hp[0]);
-      float fg = ft_sigmoid(xr[H] + hp[1]);
-      float gg = ft_tanh(xr[2 * H] + hp[2]);
-      float og = ft_sigmoid(xr[3 * H] + hp[G - 1]);
-      float cprev = s > 0 ? a.cst[op] : 0.f;
-      float c = fg * cprev + ig * gg;
+      float ig = ft_sigmoid(xg[0] + hp[0]);
+      float fg = ft_sigmoid(xg[1] + hp[1]);
+      float gg = ft_tanh(xg[2] + hp[2]);
+      float og = ft_sigmoid(xg[G - 1] + hp[G - 1]);
+      float c = fg * prev + ig * gg;
       a.cst[o] = c;
       a.out[o] = og * ft_tanh(c);
       if (gs) {
@@ -162,89 +227,91 @@ struct RnnBwdArgs {
   int B, T, H, ND, s, vec;
 };
 
-// block = 32 batch rows x 32 hidden units ; K = G*H split over NW waves
-template <int G, int NW>
+// workgroup: 16 batch rows x 16 hidden units ; K = G*H split over NW waves
+template <int G, int NW, bool FAST>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_step_kernel(RnnBwdArgs a) {
-  __shared__ float red[NW * 32 * RLD];
+  __shared__ float red[NW * 16 * RLD];
   const int d = blockIdx.z;
-  const int u0 = blockIdx.x * 32;
-  const int b0 = blockIdx.y * 32;
+  const int u0 = blockIdx.x * 16;
+  const int b0 = blockIdx.y * 16;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int half = lane >> 5, l31 = lane & 31;
+  const int q = lane >> 4, l15 = lane & 15;
   const int H = a.H, T = a.T, s = a.s, K = G * H;
   const long ldg = (long)a.ND * K;
+  const long ldo = (long)a.ND * H;
 
-  const int bA = b0 + l31;
-  int LA = T;
-  if (bA < a.B && a.lens) {
-    long l = a.lens[bA];
-    LA = l < 0 ? 0 : (l > T ? T : (int)l);
-  }
-  const bool actA = bA < a.B && s < LA && s > 0;
-  const int tnextA = d == 0 ? LA - s : s - 1;          // (t+1) with t=LA-1-s | (t-1) with t=s
-  const float* arow = a.dhp + ((long)bA * T + tnextA) * ldg + (long)d * K;
-  const bool okB = (u0 + l31) < H;
-  const float* brow = a.whhT[d] + (long)(u0 + l31) * K;
-
-  f32x16 acc;
+  // ---- cell-gradient operands of this thread (requested now, consumed after the matmul)
+  const int ci = tid >> 4, cj = tid & 15;
+  const int cb = b0 + ci, cun = u0 + cj;
+  bool cact = tid < 256 && cb < a.B && cun < H;
+  int ct = 0;
+  float gv[4] = {0.f, 0.f, 0.f, 0.f}, dov = 0.f, cin = 0.f, cc = 0.f, prev = 0.f;
+  if (cact) {
+    const int L = clamp_len(a.lens, cb, T);
+    cact = s < L;
+    if (cact) {
+      ct = d == 0 ? L - 1 - s : s;
+      const int tprev = d == 0 ? ct - 1 : ct + 1;
+      const bool has_prev = tprev >= 0 && tprev < L;
+      const long o = ((long)ct * a.B + cb) * ldo + (long)d * H + cun;
+      const long op = ((long)tprev * a.B + cb) * ldo + (long)d * H + cun;
+      const float* gs = a.gates + (((long)ct * a.B + cb) * a.ND + d) * 4 * H + cun;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const int noct = (K + 7) / 8;
-  if (s > 0) {
-
-    for (int c = wave; c < noct; c += NW) {
-      const int k = 8 * c + 4 * half;
-      float4 av = ld4g(arow + k, actA ? K - k : 0, a.vec);
-      float4 bv = ld4g(brow + k, okB ? K - k : 0, a.vec);
-      mfma4(av, bv, acc);
+      for (int g = 0; g < 4; ++g) gv[g] = gs[(long)g * H];
+      dov = a.dout[o];
+      if (s > 0) cin = a.carry[((long)cb * a.ND + d) * H + cun];
+      if (G == 3) {
+        prev = has_prev ? a.out[op] : 0.f;
+      } else {
+        cc = a.cst[o];
+        prev = has_prev ? a.cst[op] : 0.f;
+      }
     }
   }
-  store_partial(red, wave, lane, acc);
+
+  f32x4 acc[1];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[0][e] = 0.f;
+  if (s > 0) {
+    const int bA = b0 + l15;
+    const int LA = bA < a.B ? clamp_len(a.lens, bA, T) : 0;
+    const bool aok[1] = {bA < a.B && s < LA};
+    const int tnext = d == 0 ? LA - s : s - 1;           // (t+1) with t=LA-1-s | (t-1) with t=s
+    const long row = aok[0] ? (long)tnext * a.B + bA : 0;
+    const float* arow[1] = {a.dhp + row * ldg + (long)d * K};
+    const bool bok = (u0 + l15) < H;
+    const float* brow = a.whhT[d] + (bok ? (long)(u0 + l15) * K : 0);
+    const int ngroups = (K + 15) / 16;
+    const int gpw = (ngroups + NW - 1) / NW;
+    const int g0 = wave * gpw, g1 = min(ngroups, g0 + gpw);
+    wave_matmul<1, FAST>(arow, aok, brow, bok, K, g0, g1, q, a.vec, acc);
+  }
+  store_partials<1>(red, wave, lane, acc);
   __syncthreads();
 
-  for (int p = tid; p < 32 * 32; p += NW * 64) {
-    const int i = p >> 5, j = p & 31;
-    const int b = b0 + i, u = u0 + j;
-    if (b >= a.B || u >= H) continue;
-    int L = T;
-    if (a.lens) {
-      long l = a.lens[b];
-      L = l < 0 ? 0 : (l > T ? T : (int)l);
-    }
-    if (s >= L) continue;
-    const int t = d == 0 ? L - 1 - s : s;
-    const int tprev = d == 0 ? t - 1 : t + 1;
-    const bool has_prev = tprev >= 0 && tprev < L;
+  if (cact) {
     float rec = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) rec += red[w * 32 * RLD + i * RLD + j];
-    const long ldo = (long)a.ND * H;
-    const long o = ((long)b * T + t) * ldo + (long)d * H + u;
-    const long op = ((long)b * T + tprev) * ldo + (long)d * H + u;
-    const float* gs = a.gates + (((long)b * T + t) * a.ND + d) * 4 * H + u;
-    float* cr = a.carry + ((long)b * a.ND + d) * H + u;
-    const float cin = s > 0 ? *cr : 0.f;
-    float* dx = a.dxp + ((long)b * T + t) * ldg + (long)d * K + u;
+    for (int w = 0; w < NW; ++w) rec += red[w * (16 * RLD) + ci * RLD + cj];
+    float* cr = a.carry + ((long)cb * a.ND + d) * H + cun;
+    float* dx = a.dxp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
     if (G == 3) {
-      const float dh = a.dout[o] + rec + cin;
-      const float r = gs[0], z = gs[H], n = gs[2 * H], hn = gs[3 * H];
-      const float hprev = has_prev ? a.out[op] : 0.f;
-      const float dz = dh * (hprev - n) * z * (1.f - z);
+      const float dh = dov + rec + cin;
+      const float r = gv[0], z = gv[1], n = gv[2], hn = gv[3];
+      const float dz = dh * (prev - n) * z * (1.f - z);
       const float dn = dh * (1.f - z) * (1.f - n * n);
       const float dr = dn * hn * r * (1.f - r);
       dx[0] = dr; dx[H] = dz; dx[2 * H] = dn;
-      float* dhh = a.dhp + ((long)b * T + t) * ldg + (long)d * K + u;
+      float* dhh = a.dhp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
       dhh[0] = dr; dhh[H] = dz; dhh[2 * H] = dn * r;
       *cr = dh * z;
     } else {
-      const float dh = a.dout[o] + rec;
-      const float ig = gs[0], fg = gs[H], gg = gs[2 * H], og = gs[3 * H];
-      const float c = a.cst[o];
-      const float cprev = has_prev ? a.cst[op] : 0.f;
-      const float tc = ft_tanh(c);
+      const float dh = dov + rec;
+      const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+      const float tc = ft_tanh(cc);
       const float dc = dh * og * (1.f - tc * tc) + cin;
       dx[0] = dc * gg * ig * (1.f - ig);
-      dx[H] = dc * cprev * fg * (1.f - fg);
+      dx[H] = dc * prev * fg * (1.f - fg);
       dx[2 * H] = dc * ig * (1.f - gg * gg);
       dx[3 * H] = dh * tc * og * (1.f - og);
       *cr = dc * fg;
@@ -253,14 +320,32 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_step_kernel(RnnBwdArgs a) 
 }
 
 // out[b,t,:] = t < len[b] ? raw[b,t,:] : pad      (pad_packed_sequence padding_value, forward_tacotron.py:152)
+// raw is TIME-major [T,B,C] (the recurrence's layout), out is batch-major [B,T,C]
 __global__ void ft_fill_padded_kernel(const float* __restrict__ raw, const long* __restrict__ lens,
                                       float* __restrict__ out, int B, int T, int C, float pad) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)B * T * C;
   if (i >= total) return;
   long row = i / C;
+  int c = (int)(i - row * C);
   int b = (int)(row / T), t = (int)(row - (long)b * T);
-  out[i] = t < lens[b] ? raw[i] : pad;
+  out[i] = (!lens || t < lens[b]) ? raw[((long)t * B + b) * C + c] : pad;
+}
+// [B,T,C] <-> [T,B,C] row permutation (dst_time_major: dst is [T,B,C])
+__global__ void ft_bt_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int T, int C,
+                                       int dst_time_major) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * T * C;
+  if (i >= total) return;
+  long row = i / C;
+  int c = (int)(i - row * C);
+  if (dst_time_major) {
+    int t = (int)(row / B), b = (int)(row - (long)t * B);
+    dst[i] = src[((long)b * T + t) * C + c];
+  } else {
+    int b = (int)(row / T), t = (int)(row - (long)b * T);
+    dst[i] = src[((long)t * B + b) * C + c];
+  }
 }
 // dst = t < len[b] ? src : 0
 __global__ void ft_mask_rows_kernel(const float* __restrict__ src, const long* __restrict__ lens,
@@ -273,6 +358,14 @@ __global__ void ft_mask_rows_kernel(const float* __restrict__ src, const long* _
   dst[i] = t < lens[b] ? src[i] : 0.f;
 }
 
+template <int G, int NW, int MT>
+void launch_fwd(bool fast, dim3 grid, hipStream_t stream, const RnnFwdArgs& a) {
+  if (fast)
+    hipLaunchKernelGGL((ft_rnn_fwd_step_kernel<G, NW, MT, true>), grid, dim3(NW * 64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((ft_rnn_fwd_step_kernel<G, NW, MT, false>), grid, dim3(NW * 64), 0, stream, a);
+}
+
 template <int G>
 int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
             float* out, float* cst, float* gates, const long* lens, int B, int T, int H, hipStream_t stream) {
@@ -281,16 +374,30 @@ int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float
   a.out = out; a.cst = cst; a.gates = gates; a.lens = lens;
   a.B = B; a.T = T; a.H = H; a.ND = 2;
   a.vec = (H % 4 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)whh_f % 16 == 0) && ((uintptr_t)whh_r % 16 == 0);
-  dim3 grid(ft_cdiv(H, U), ft_cdiv(B, 32), 2);
-  const bool wide = H > 256;
+  const bool fast = a.vec && (H % 16 == 0);
+  constexpr int UB = 16 / G;
+  const bool two = B > 16;                        // 32 batch rows per workgroup when there are that many
+  dim3 grid(ft_cdiv(H, UB), ft_cdiv(B, two ? 32 : 16), 2);
+  const int ngroups = ft_cdiv(H, 16);
   for (int s = 0; s < T; ++s) {
     a.s = s;
-    if (wide)
-      hipLaunchKernelGGL((ft_rnn_fwd_step_kernel<G, 8>), grid, dim3(512), 0, stream, a);
-    else
-      hipLaunchKernelGGL((ft_rnn_fwd_step_kernel<G, 4>), grid, dim3(256), 0, stream, a);
+    if (ngroups > 16) {
+      if (two) launch_fwd<G, 8, 2>(fast, grid, stream, a);
+      else launch_fwd<G, 8, 1>(fast, grid, stream, a);
+    } else {
+      if (two) launch_fwd<G, 4, 2>(fast, grid, stream, a);
+      else launch_fwd<G, 4, 1>(fast, grid, stream, a);
+    }
   }
   return ft_check_launch("rnn_fwd");
+}
+
+template <int G, int NW>
+void launch_bwd(bool fast, dim3 grid, hipStream_t stream, const RnnBwdArgs& a) {
+  if (fast)
+    hipLaunchKernelGGL((ft_rnn_bwd_step_kernel<G, NW, true>), grid, dim3(NW * 64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((ft_rnn_bwd_step_kernel<G, NW, false>), grid, dim3(NW * 64), 0, stream, a);
 }
 
 template <int G>
@@ -303,14 +410,14 @@ int rnn_bwd(const float* dout, const float* out, const float* cst, const float* 
   a.B = B; a.T = T; a.H = H; a.ND = 2;
   a.vec = (H % 4 == 0) && ((uintptr_t)dhp % 16 == 0) && ((uintptr_t)whhT_f % 16 == 0) &&
           ((uintptr_t)whhT_r % 16 == 0);
-  dim3 grid(ft_cdiv(H, 32), ft_cdiv(B, 32), 2);
-  const bool wide = (long)G * H > 1024;
+  const bool fast = a.vec && (((long)G * H) % 16 == 0);
+  dim3 grid(ft_cdiv(H, 16), ft_cdiv(B, 16), 2);
+  const int ngroups = ft_cdiv((long)G * H, 16);
   for (int s = 0; s < T; ++s) {
     a.s = s;
-    if (wide)
-      hipLaunchKernelGGL((ft_rnn_bwd_step_kernel<G, 16>), grid, dim3(1024), 0, stream, a);
-    else
-      hipLaunchKernelGGL((ft_rnn_bwd_step_kernel<G, 8>), grid, dim3(512), 0, stream, a);
+    if (ngroups > 64) launch_bwd<G, 16>(fast, grid, stream, a);
+    else if (ngroups > 16) launch_bwd<G, 8>(fast, grid, stream, a);
+    else launch_bwd<G, 4>(fast, grid, stream, a);
   }
   return ft_check_launch("rnn_bwd");
 }
@@ -358,6 +465,14 @@ int ft_fill_padded(const float* raw, const long* lens, float* out, int B, int T,
   hipLaunchKernelGGL(ft_fill_padded_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, raw, lens,
                      out, B, T, C, pad);
   return ft_check_launch("fill_padded");
+}
+
+int ft_bt_transpose(const float* src, float* dst, int B, int T, int C, int dst_time_major, void* stream) {
+  long total = (long)B * T * C;
+  if (total <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_bt_transpose_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
+                     T, C, dst_time_major);
+  return ft_check_launch("bt_transpose");
 }
 
 int ft_mask_rows(const float* src, const long* lens, float* dst, int B, int T, int C, void* stream) {

@@ -54,28 +54,38 @@ def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
 # linear
 # ---------------------------------------------------------------------------------------------------
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [..., in] , w [out, in] -> [..., out]"""
+               out: Optional[torch.Tensor] = None, x_tm_B: int = 0, y_tm_B: int = 0) -> torch.Tensor:
+    """x [..., in] , w [out, in] -> [..., out].  x_tm_B / y_tm_B > 0: that side is time-major [T,B,*]
+    (see include/fwdtaco_hip.h, "Row layouts"); a layout change swaps the two leading dims of the result."""
     _chk(x, 'x'); _chk(w, 'w')
     in_f = x.shape[-1]
     rows = x.numel() // max(in_f, 1) if in_f else 0
     out_f = w.shape[0]
     assert w.shape[1] == in_f
-    y = out if out is not None else torch.empty(*x.shape[:-1], out_f, device=x.device, dtype=x.dtype)
+    if out is not None:
+        y = out
+    elif bool(x_tm_B) != bool(y_tm_B):
+        Bq = x_tm_B or y_tm_B
+        lead = (rows // Bq, Bq) if y_tm_B else (Bq, rows // Bq)
+        y = torch.empty(*lead, out_f, device=x.device, dtype=x.dtype)
+    else:
+        y = torch.empty(*x.shape[:-1], out_f, device=x.device, dtype=x.dtype)
     _lib.call('ft_linear_fwd', _p(x), in_f, _p(w), _p(bias), _p(y), out_f, rows, in_f, out_f, int(relu), 0,
-              _stream())
+              x_tm_B, y_tm_B, _stream())
     return y
 
 
 def linear_multi_fwd(x: torch.Tensor, ws: List[torch.Tensor], biases: Optional[List[Optional[torch.Tensor]]],
-                     relu: bool = False) -> torch.Tensor:
-    """Several Linear layers on one input, outputs concatenated along the last dim (one launch)."""
+                     relu: bool = False, y_tm_B: int = 0) -> torch.Tensor:
+    """Several Linear layers on one (batch-major) input, outputs concatenated along the last dim (one launch).
+    y_tm_B > 0: x is [B,T,in] and the result is written time-major [T,B,sum(out)]."""
     _chk(x, 'x')
     in_f = x.shape[-1]
     rows = x.numel() // max(in_f, 1)
     outs = [int(w.shape[0]) for w in ws]
     offs = [sum(outs[:i]) for i in range(len(outs))]
-    y = torch.empty(*x.shape[:-1], sum(outs), device=x.device, dtype=x.dtype)
+    lead = (rows // y_tm_B, y_tm_B) if y_tm_B else tuple(x.shape[:-1])
+    y = torch.empty(*lead, sum(outs), device=x.device, dtype=x.dtype)
     n = len(ws)
     wa = _ptr_array(ws)
     ba = _ptr_array(biases) if biases is not None else None
@@ -83,37 +93,43 @@ def linear_multi_fwd(x: torch.Tensor, ws: List[torch.Tensor], biases: Optional[L
     fa = (ctypes.c_int * n)(*outs)
     _lib.call('ft_linear_multi_fwd', _p(x), in_f, n, ctypes.cast(wa, c_void_p),
               ctypes.cast(ba, c_void_p) if ba is not None else None, _p(y), sum(outs),
-              ctypes.cast(oa, c_void_p), ctypes.cast(fa, c_void_p), rows, in_f, int(relu), _stream())
+              ctypes.cast(oa, c_void_p), ctypes.cast(fa, c_void_p), rows, in_f, int(relu), 0, y_tm_B, _stream())
     return y
 
 
-def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, lddy: Optional[int] = None, out_f: Optional[int] = None,
-                    dx: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """dx = dy[..., :out_f] @ w ; dy may be a column slice of a wider buffer (pass lddy/out_f + a pointer view)."""
-    _chk(w, 'w')
-    out_f = out_f if out_f is not None else dy.shape[-1]
-    lddy = lddy if lddy is not None else dy.shape[-1]
+def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, dx: Optional[torch.Tensor] = None, accumulate: bool = False,
+                    dy_tm_B: int = 0, dx_tm_B: int = 0) -> torch.Tensor:
+    """dx = dy @ w ; *_tm_B > 0: that side is time-major."""
+    _chk(w, 'w'); _chk(dy, 'dy')
+    out_f = dy.shape[-1]
     in_f = w.shape[1]
-    rows = dy.numel() // dy.shape[-1] if lddy == dy.shape[-1] else None
-    assert rows is not None
+    rows = dy.numel() // max(out_f, 1)
     if dx is None:
-        dx = torch.empty(*dy.shape[:-1], in_f, device=dy.device, dtype=dy.dtype)
-    _lib.call('ft_linear_bwd_data', _p(dy), lddy, _p(w), _p(dx), in_f, rows, in_f, out_f, int(accumulate), _stream())
+        if bool(dy_tm_B) != bool(dx_tm_B):
+            Bq = dy_tm_B or dx_tm_B
+            lead = (rows // Bq, Bq) if dx_tm_B else (Bq, rows // Bq)
+        else:
+            lead = tuple(dy.shape[:-1])
+        dx = torch.empty(*lead, in_f, device=dy.device, dtype=dy.dtype)
+    _lib.call('ft_linear_bwd_data', _p(dy), out_f, _p(w), _p(dx), in_f, rows, in_f, out_f, int(accumulate),
+              dy_tm_B, dx_tm_B, _stream())
     return dx
 
 
 def linear_bwd_data_raw(dy_ptr: int, lddy: int, w: torch.Tensor, dx: torch.Tensor, rows: int, out_f: int,
-                        accumulate: bool) -> None:
+                        accumulate: bool, dy_tm_B: int = 0, dx_tm_B: int = 0) -> None:
     in_f = w.shape[1]
-    _lib.call('ft_linear_bwd_data', dy_ptr, lddy, _p(w), _p(dx), in_f, rows, in_f, out_f, int(accumulate), _stream())
+    _lib.call('ft_linear_bwd_data', dy_ptr, lddy, _p(w), _p(dx), in_f, rows, in_f, out_f, int(accumulate),
+              dy_tm_B, dx_tm_B, _stream())
 
 
 def linear_bwd_weight_raw(dy_ptr: int, lddy: int, x_ptr: int, ldx: int, dw: torch.Tensor, rows: int, in_f: int,
-                          out_f: int, B: int = 1, T: int = 0, x_shift: int = 0, accumulate: bool = False) -> None:
+                          out_f: int, B: int = 1, T: int = 0, x_shift: int = 0, accumulate: bool = False,
+                          dy_tm: bool = False, x_tm: bool = False) -> None:
     nbytes = _lib.query('ft_linear_bwd_weight_workspace', rows, in_f, out_f)
     ws = workspace(nbytes, dw.device)
     _lib.call('ft_linear_bwd_weight', dy_ptr, lddy, x_ptr, ldx, _p(dw), rows, in_f, out_f, B, T if T else rows,
-              x_shift, int(accumulate), _p(ws), ws.numel(), _stream())
+              x_shift, int(accumulate), int(dy_tm), int(x_tm), _p(ws), ws.numel(), _stream())
 
 
 def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -319,11 +335,28 @@ def check_index_errors(device) -> None:
         raise IndexError('embedding index out of range (set by ft_embedding_fwd)')
 
 
-def embedding_bwd(idx: torch.Tensor, dout: torch.Tensor, V: int) -> torch.Tensor:
+def onehot(idx: torch.Tensor, V: int) -> torch.Tensor:
+    _chk(idx, 'idx', torch.int64)
+    out = torch.empty(idx.numel(), V, device=idx.device, dtype=torch.float32)
+    _lib.call('ft_onehot', _p(idx), _p(out), idx.numel(), V, _stream())
+    return out
+
+
+def embedding_bwd(idx: torch.Tensor, dout: torch.Tensor, V: int,
+                  onehot_cache: Optional[dict] = None) -> torch.Tensor:
+    """dW[V,C] = onehot(idx)^T @ dout (TN MFMA GEMM).  onehot_cache lets the four embedding tables that
+    share one id tensor (main + three predictors) build the one-hot matrix once."""
     _chk(idx, 'idx', torch.int64); _chk(dout, 'dout')
     C = dout.shape[-1]
+    key = (idx.data_ptr(), idx.numel(), V)
+    oh = onehot_cache.get(key) if onehot_cache is not None else None
+    if oh is None:
+        oh = onehot(idx, V)
+        if onehot_cache is not None:
+            onehot_cache.clear()
+            onehot_cache[key] = oh
     dw = torch.empty(V, C, device=dout.device, dtype=dout.dtype)
-    _lib.call('ft_embedding_bwd', _p(idx), _p(dout), _p(dw), idx.numel(), C, V, _stream())
+    linear_bwd_weight_raw(_p(oh), V, _p(dout), C, dw, idx.numel(), C, V)
     return dw
 
 
@@ -360,12 +393,14 @@ def maxpool2_bwd(dout: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def cond_add_fwd(x, pitch, energy, wp, bp, we, be, sp: float, se: float) -> torch.Tensor:
+def cond_add_fwd(x, pitch, energy, wp, bp, we, be, sp: float, se: float, x_time_major: bool = False) -> torch.Tensor:
+    """x [B,T,C] (or time-major [T,B,C]) -> batch-major [B,T,C]"""
     _chk(x, 'x'); _chk(pitch, 'pitch'); _chk(energy, 'energy')
-    B, T, C = x.shape
-    out = torch.empty_like(x)
+    B, T = pitch.shape
+    C = x.shape[-1]
+    out = torch.empty(B, T, C, device=x.device, dtype=x.dtype)
     _lib.call('ft_cond_add_fwd', _p(x), _p(pitch), _p(energy), _p(wp), _p(bp), _p(we), _p(be), sp, se, _p(out), B,
-              T, C, _stream())
+              T, C, int(x_time_major), _stream())
     return out
 
 
@@ -420,11 +455,12 @@ def masked_l1_bwd(x, target, lens, inv, grad_out: Optional[torch.Tensor], factor
 # ---------------------------------------------------------------------------------------------------
 # recurrences
 # ---------------------------------------------------------------------------------------------------
+# All recurrence buffers are TIME-major: xp [T,B,2*G*H], out / cstate [T,B,2H], gates [T,B,2,4H].
 def gru_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool):
     _chk(xp, 'xp')
-    B, T, _ = xp.shape
-    out = torch.empty(B, T, 2 * H, device=xp.device, dtype=xp.dtype)
-    gates = torch.empty(B, T, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
+    T, B, _ = xp.shape
+    out = torch.empty(T, B, 2 * H, device=xp.device, dtype=xp.dtype)
+    gates = torch.empty(T, B, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
     _lib.call('ft_gru_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(out), _p(gates), B, T, H,
               _stream())
     return out, gates
@@ -432,9 +468,9 @@ def gru_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool):
 
 def gru_bwd(dout, out, gates, whhT_f, whhT_r, H: int):
     _chk(dout, 'dout')
-    B, T, _ = out.shape
-    dxp = torch.empty(B, T, 6 * H, device=out.device, dtype=out.dtype)
-    dhp = torch.empty(B, T, 6 * H, device=out.device, dtype=out.dtype)
+    T, B, _ = out.shape
+    dxp = torch.empty(T, B, 6 * H, device=out.device, dtype=out.dtype)
+    dhp = torch.empty(T, B, 6 * H, device=out.device, dtype=out.dtype)
     carry = torch.empty(B, 2, H, device=out.device, dtype=out.dtype)
     _lib.call('ft_gru_bwd', _p(dout), _p(out), _p(gates), _p(whhT_f), _p(whhT_r), _p(dxp), _p(dhp), _p(carry), B, T,
               H, _stream())
@@ -443,10 +479,10 @@ def gru_bwd(dout, out, gates, whhT_f, whhT_r, H: int):
 
 def lstm_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, lens: Optional[torch.Tensor], H: int, save_gates: bool):
     _chk(xp, 'xp')
-    B, T, _ = xp.shape
-    raw = torch.empty(B, T, 2 * H, device=xp.device, dtype=xp.dtype)
-    cst = torch.empty(B, T, 2 * H, device=xp.device, dtype=xp.dtype)
-    gates = torch.empty(B, T, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
+    T, B, _ = xp.shape
+    raw = torch.empty(T, B, 2 * H, device=xp.device, dtype=xp.dtype)
+    cst = torch.empty(T, B, 2 * H, device=xp.device, dtype=xp.dtype)
+    gates = torch.empty(T, B, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
     _lib.call('ft_lstm_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(lens), _p(raw), _p(cst),
               _p(gates), B, T, H, _stream())
     return raw, cst, gates
@@ -454,19 +490,33 @@ def lstm_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, lens: Optional[torch.Tensor], H: in
 
 def lstm_bwd(dout, raw, cst, gates, whhT_f, whhT_r, lens: Optional[torch.Tensor], H: int):
     _chk(dout, 'dout')
-    B, T, _ = raw.shape
-    dg = torch.empty(B, T, 8 * H, device=raw.device, dtype=raw.dtype)
+    T, B, _ = raw.shape
+    dg = torch.empty(T, B, 8 * H, device=raw.device, dtype=raw.dtype)
     carry = torch.empty(B, 2, H, device=raw.device, dtype=raw.dtype)
     _lib.call('ft_lstm_bwd', _p(dout), _p(raw), _p(cst), _p(gates), _p(whhT_f), _p(whhT_r), _p(lens), _p(dg),
               _p(carry), B, T, H, _stream())
     return dg
 
 
-def fill_padded(raw: torch.Tensor, lens: torch.Tensor, pad: float) -> torch.Tensor:
-    B, T, C = raw.shape
-    out = torch.empty_like(raw)
-    _lib.call('ft_fill_padded', _p(raw), _p(lens), _p(out), B, T, C, pad, _stream())
+def fill_padded(raw_tm: torch.Tensor, lens: Optional[torch.Tensor], pad: float) -> torch.Tensor:
+    """time-major raw [T,B,C] -> batch-major [B,T,C] with `pad` at t >= lens[b] (lens None: pure layout change)"""
+    T, B, C = raw_tm.shape
+    out = torch.empty(B, T, C, device=raw_tm.device, dtype=raw_tm.dtype)
+    _lib.call('ft_fill_padded', _p(raw_tm), _p(lens), _p(out), B, T, C, pad, _stream())
     return out
+
+
+def bt_transpose(src: torch.Tensor, to_time_major: bool) -> torch.Tensor:
+    """[B,T,C] -> [T,B,C] (to_time_major) or [T,B,C] -> [B,T,C]"""
+    _chk(src, 'src')
+    if to_time_major:
+        B, T, C = src.shape
+        dst = torch.empty(T, B, C, device=src.device, dtype=src.dtype)
+    else:
+        T, B, C = src.shape
+        dst = torch.empty(B, T, C, device=src.device, dtype=src.dtype)
+    _lib.call('ft_bt_transpose', _p(src), _p(dst), B, T, C, int(to_time_major), _stream())
+    return dst
 
 
 def mask_rows(src: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:

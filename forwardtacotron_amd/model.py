@@ -60,8 +60,11 @@ class GRU(_RNNParams):
     def __init__(self, input_size: int, hidden_size: int) -> None:
         super().__init__(input_size, hidden_size, 3)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.BiGRUFn.apply(x, *self.weights())
+    def forward(self, x: torch.Tensor, time_major_out: bool = False) -> torch.Tensor:
+        """x [B,T,in] -> [B,T,2H]; time_major_out=True returns the recurrence's native [T,B,2H] layout
+        (what the fused consumers inside this package read directly)."""
+        y = ops.BiGRUFn.apply(x, *self.weights())
+        return y if time_major_out else ops.BTTransposeFn.apply(y, False)
 
 
 class LSTM(_RNNParams):
@@ -169,7 +172,7 @@ class CBHG(nn.Module):
             out.append(ts[0].detach().as_strided((K * C,), (1,)))
         return out
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, time_major_out: bool = False) -> torch.Tensor:
         K = len(self.bank_kernels)
         C = self.conv1d_bank[0].conv.weight.shape[0]
         gamma, beta, rm, rv = self._bank_flat()
@@ -190,7 +193,7 @@ class CBHG(nn.Module):
         y = ops.LinearFn.apply(y, self.pre_highway.weight, None)
         for h in self.highways:
             y = h(y)
-        return self.rnn(y)
+        return self.rnn(y, time_major_out=time_major_out)
 
 
 class SeriesPredictor(nn.Module):
@@ -213,8 +216,9 @@ class SeriesPredictor(nn.Module):
         for conv in self.convs:
             x = conv(x)
             x = _dropout(x, self.dropout, self.training)
-        x = self.rnn(x)
-        x = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)
+        B = x.shape[0]
+        x = self.rnn(x, time_major_out=True)
+        x = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias, B)       # [T,B,2H] -> [B,T,1]
         if alpha != 1.0:
             x = ops.ScaleFn.apply(x, 1.0 / alpha)
         return x
@@ -288,16 +292,17 @@ class ForwardTacotron(nn.Module):
 
     def _trunk(self, x: torch.Tensor, dur: torch.Tensor, pitch: torch.Tensor, energy: torch.Tensor,
                mel_lens: Optional[torch.Tensor]):
+        B = x.shape[0]
         x = ops.EmbeddingFn.apply(x, self.embedding.weight)
-        x = self.prenet(x)
+        x = self.prenet(x, time_major_out=True)                             # [Tx,B,2P] (recurrence layout)
         x = ops.CondAddFn.apply(x, pitch, energy, self.pitch_proj.weight, self.pitch_proj.bias,
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
-                                self.energy_strength)
+                                self.energy_strength, True)                 # -> [B,Tx,2P]
         x = self.lr(x, dur)
         x = self.lstm(x, mel_lens, self.padding_value)
         mel = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)        # [B,T,n_mels]
-        post = self.postnet(mel)
-        post = ops.LinearFn.apply(post, self.post_proj.weight, None)
+        post = self.postnet(mel, time_major_out=True)                       # [T,B,2Q]
+        post = ops.LinearFn.apply(post, self.post_proj.weight, None, B)     # -> [B,T,n_mels]
         return mel, post
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

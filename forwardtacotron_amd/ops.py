@@ -22,37 +22,64 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 class EmbeddingFn(Function):
     """nn.Embedding (forward_tacotron.py:18,73)."""
 
+    _onehot_cache: dict = {}
+
     @staticmethod
     def forward(ctx, idx, w):
         idx = _c(idx)
         ctx.save_for_backward(idx)
         ctx.V = w.shape[0]
+        EmbeddingFn._onehot_cache.clear()      # ids may have changed in place since the last step
         return H.embedding_fwd(idx, w)
 
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        return None, H.embedding_bwd(idx, _c(dout), ctx.V)
+        return None, H.embedding_bwd(idx, _c(dout), ctx.V, EmbeddingFn._onehot_cache)
 
 
 class LinearFn(Function):
-    """nn.Linear over the last dim (forward_tacotron.py:25,100,108 ; common_layers.py:83)."""
+    """nn.Linear over the last dim (forward_tacotron.py:25,100,108 ; common_layers.py:83).
+    x_tm_B > 0: x is a TIME-major [T,B,in] recurrence output; the result is batch-major [B,T,out] and the
+    gradient handed back to the recurrence is time-major again (no transposition pass either way)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, x_tm_B=0):
         x = _c(x)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return H.linear_fwd(x, w, b)
+        ctx.tmB = int(x_tm_B)
+        return H.linear_fwd(x, w, b, x_tm_B=ctx.tmB, y_tm_B=0)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = _c(dy)
-        dx = H.linear_bwd_data(dy, w) if ctx.needs_input_grad[0] else None
-        dw = H.linear_bwd_weight(dy, x)
+        tmB = ctx.tmB
+        dx = H.linear_bwd_data(dy, w, dy_tm_B=0, dx_tm_B=tmB) if ctx.needs_input_grad[0] else None
+        if tmB:
+            out_f, in_f = w.shape
+            rows = x.numel() // in_f
+            dw = torch.empty_like(w)
+            H.linear_bwd_weight_raw(dy.data_ptr(), out_f, x.data_ptr(), in_f, dw, rows, in_f, out_f, B=tmB,
+                                    T=rows // tmB, dy_tm=False, x_tm=True)
+        else:
+            dw = H.linear_bwd_weight(dy, x)
         db = H.colsum(dy) if ctx.has_bias else None
-        return dx, dw, db
+        return dx, dw, db, None
+
+
+class BTTransposeFn(Function):
+    """[B,T,C] <-> [T,B,C] layout change (only needed when a recurrence output leaves the fused path)."""
+
+    @staticmethod
+    def forward(ctx, x, to_time_major):
+        ctx.to_tm = bool(to_time_major)
+        return H.bt_transpose(_c(x), ctx.to_tm)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return H.bt_transpose(_c(dy), not ctx.to_tm), None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -200,7 +227,8 @@ class HighwayFn(Function):
 # ---------------------------------------------------------------------------------------------------
 def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, w_ih_f, w_ih_r, need_dx):
     """Shared tail of the GRU/LSTM backward: weight / bias / input gradients from the per-step
-    pre-activation gradients (dxp wrt input projection, dhp wrt hidden projection)."""
+    pre-activation gradients (dxp wrt input projection, dhp wrt hidden projection).
+    x is batch-major [B,T,I]; dxp / dhp / hid are the recurrence's time-major [T,B,*] buffers."""
     B, T, I = x.shape
     rows = B * T
     GH = G * Hh
@@ -212,25 +240,26 @@ def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, w_ih_f, w_ih_r, need_dx):
         px = dxp.data_ptr() + d * GH * _F4
         ph = dhp.data_ptr() + d * GH * _F4
         dw_ih = torch.empty(GH, I, device=x.device, dtype=x.dtype)
-        H.linear_bwd_weight_raw(px, 2 * GH, x.data_ptr(), I, dw_ih, rows, I, GH)
+        H.linear_bwd_weight_raw(px, 2 * GH, x.data_ptr(), I, dw_ih, rows, I, GH, B=B, T=T, dy_tm=True, x_tm=False)
         dw_hh = torch.empty(GH, Hh, device=x.device, dtype=x.dtype)
         H.linear_bwd_weight_raw(ph, 2 * GH, hid.data_ptr() + d * Hh * _F4, 2 * Hh, dw_hh, rows, Hh, GH, B=B, T=T,
-                                x_shift=-1 if d == 0 else 1)
+                                x_shift=-1 if d == 0 else 1, dy_tm=True, x_tm=True)
         if dx is not None:
-            H.linear_bwd_data_raw(px, 2 * GH, w_ih, dx, rows, GH, d > 0)
+            H.linear_bwd_data_raw(px, 2 * GH, w_ih, dx, rows, GH, d > 0, dy_tm_B=B, dx_tm_B=0)
         grads.append((dw_ih, dw_hh, dbx[d * GH:(d + 1) * GH], dbh[d * GH:(d + 1) * GH]))
     return dx, grads
 
 
 class BiGRUFn(Function):
-    """nn.GRU(bidirectional=True, batch_first=True), h0=0 (common_layers.py:89,123)."""
+    """nn.GRU(bidirectional=True, batch_first=True), h0=0 (common_layers.py:89,123).
+    x is batch-major [B,T,I]; the result (and the gradient it expects) is TIME-major [T,B,2H]."""
 
     @staticmethod
     def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         x = _c(x)
         Hh = w_hh_f.shape[1]
         train = any(ctx.needs_input_grad)
-        xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r])
+        xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
         out, gates = H.gru_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, Hh, save_gates=train)
         if train:
             ctx.save_for_backward(x, out, gates, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
@@ -255,20 +284,21 @@ class BiLSTMFn(Function):
         x = _c(x)
         Hh = w_hh_f.shape[1]
         train = any(ctx.needs_input_grad)
-        xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r])
+        xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
         raw, cst, gates = H.lstm_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens, Hh, save_gates=train)
         if train:
             ctx.save_for_backward(x, raw, cst, gates, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens)
         ctx.Hh = Hh
         ctx.has_lens = lens is not None
-        return H.fill_padded(raw, lens, float(pad_value)) if lens is not None else raw
+        # time-major raw states -> batch-major output, padding_value beyond each item's length
+        return H.fill_padded(raw, lens, float(pad_value))
 
     @staticmethod
     def backward(ctx, dout):
         x, raw, cst, gates, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens = ctx.saved_tensors
         Hh = ctx.Hh
-        dg = H.lstm_bwd(_c(dout), raw, cst, gates, H.transpose2d(w_hh_f), H.transpose2d(w_hh_r),
-                        lens if ctx.has_lens else None, Hh)
+        dg = H.lstm_bwd(H.bt_transpose(_c(dout), True), raw, cst, gates, H.transpose2d(w_hh_f),
+                        H.transpose2d(w_hh_r), lens if ctx.has_lens else None, Hh)
         dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, w_ih_f, w_ih_r, ctx.needs_input_grad[0])
         return (dx, None, None, g[0][0], g[0][1], g[0][2], g[0][3], g[1][0], g[1][1], g[1][2], g[1][3])
 
@@ -278,12 +308,13 @@ class CondAddFn(Function):
     """x + pitch_proj(pitch)*s_p + energy_proj(energy)*s_e  (forward_tacotron.py:137-143)."""
 
     @staticmethod
-    def forward(ctx, x, pitch, energy, wp, bp, we, be, sp, se):
+    def forward(ctx, x, pitch, energy, wp, bp, we, be, sp, se, x_time_major=False):
         x, pitch, energy = _c(x), _c(pitch), _c(energy)
         ctx.save_for_backward(pitch, energy)
         ctx.sp, ctx.se = float(sp), float(se)
         ctx.C = x.shape[-1]
-        return H.cond_add_fwd(x, pitch, energy, wp, bp, we, be, float(sp), float(se))
+        ctx.x_tm = bool(x_time_major)
+        return H.cond_add_fwd(x, pitch, energy, wp, bp, we, be, float(sp), float(se), ctx.x_tm)
 
     @staticmethod
     def backward(ctx, dout):
@@ -296,7 +327,8 @@ class CondAddFn(Function):
         dbp = g[:, 3] * ctx.sp
         dwe = (g[:, 4:7] * ctx.se).reshape(C, 1, 3)
         dbe = g[:, 7] * ctx.se
-        return dout, None, None, dwp, dbp, dwe, dbe, None, None
+        dx = H.bt_transpose(dout, True) if ctx.x_tm else dout
+        return dx, None, None, dwp, dbp, dwe, dbe, None, None, None
 
 
 class LengthRegulateFn(Function):

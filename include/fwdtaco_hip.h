@@ -31,23 +31,28 @@ int ft_abi_version(void);
 int ft_device_info(int* cu_count, int* is_gfx950);
 
 /* ---- nn.Linear (models/forward_tacotron.py:25,100,108 ; common_layers.py:31-32,83) ------------------ */
-/* y[rows,out_f] (+)= x[rows,in_f] * w[out_f,in_f]^T + bias ; optional relu */
+/* Row layouts: the rows of an activation matrix are the (b,t) positions in batch-major order (row = b*T+t,
+ * i.e. a contiguous [B,T,C] tensor) unless a `*_tm_B` argument is > 0, in which case that operand is stored
+ * TIME-major ([T,B,C], row = t*B+b, B = the argument; rows % B == 0).  The recurrences keep their buffers
+ * time-major (each timestep's slab contiguous); the GEMMs read / write either order for free.
+ * y[rows,out_f] (+)= x[rows,in_f] * w[out_f,in_f]^T + bias ; optional relu */
 int ft_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy, int rows,
-                  int in_f, int out_f, int relu, int accumulate, void* stream);
+                  int in_f, int out_f, int relu, int accumulate, int x_tm_B, int y_tm_B, void* stream);
 /* several Linear layers sharing one input, written side by side into y (highway W1|W2, RNN fwd|rev W_ih):
  * y[:, col_offset[i] : col_offset[i]+out_f[i]] = x * w[i]^T + bias[i]   (host arrays of device pointers) */
 int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
                         float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
-                        void* stream);
+                        int x_tm_B, int y_tm_B, void* stream);
 /* dx[rows,in_f] (+)= dy[rows,out_f] * w[out_f,in_f] */
 int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, long lddx, int rows, int in_f,
-                       int out_f, int accumulate, void* stream);
+                       int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream);
 /* dw[out_f,in_f] (+)= dy^T * shift(x): rows = B*T logical positions; x_shift != 0 reads x row (b, t+x_shift),
- * zero outside [0,T) (recurrent-weight gradients: h_{t-1} / h_{t+1}).  Deterministic split + ordered reduce. */
+ * zero outside [0,T) (recurrent-weight gradients: h_{t-1} / h_{t+1}); dy_time_major / x_time_major = 1 when
+ * that operand is stored [T,B,*].  Deterministic split + ordered reduce. */
 size_t ft_linear_bwd_weight_workspace(int rows, int in_f, int out_f);
 int ft_linear_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int rows, int in_f,
-                         int out_f, int B, int T, int x_shift, int accumulate, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         int out_f, int B, int T, int x_shift, int accumulate, int dy_time_major, int x_time_major,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- nn.Conv1d(stride 1, padding k//2, bias=False) of BatchNormConv (common_layers.py:50,55-56) ------ */
 /* weights are consumed TAP-MAJOR: wp[k][Cout][Cin] (ft_conv_pack_weight from torch's [Cout][Cin][k]).
@@ -114,7 +119,8 @@ int ft_scale(const float* x, float* out, long n, float s, void* stream);
 /* out[row,:] = w[idx[row],:] ; *err_flag set to 1 on an out-of-range index (row zero-filled) */
 int ft_embedding_fwd(const long* idx, const float* w, float* out, long rows, int C, int V, int* err_flag,
                      void* stream);
-int ft_embedding_bwd(const long* idx, const float* dout, float* dw, long rows, int C, int V, void* stream);
+/* backward: onehot[rows,V] = (idx == v); dW[V,C] = onehot^T * dout via ft_linear_bwd_weight (ordered, reproducible) */
+int ft_onehot(const long* idx, float* out, long rows, int V, void* stream);
 
 /* ---- HighwayNetwork gate (common_layers.py:35-40); x12 = [W1 x + b1 | W2 x + b2] from ft_linear_multi_fwd */
 int ft_highway_gate_fwd(const float* x12, const float* x, float* out, long rows, int C, void* stream);
@@ -129,7 +135,7 @@ int ft_maxpool2_bwd(const float* dout, const float* x, float* dx, int B, int T, 
 /* ---- pitch/energy conditioning (forward_tacotron.py:111-112,137-143): Conv1d(1->C,k3,p1)+bias, scaled add */
 int ft_cond_add_fwd(const float* x, const float* pitch, const float* energy, const float* w_pitch,
                     const float* b_pitch, const float* w_energy, const float* b_energy, float pitch_strength,
-                    float energy_strength, float* out, int B, int T, int C, void* stream);
+                    float energy_strength, float* out, int B, int T, int C, int x_time_major, void* stream);
 /* taps[row][8] = [p[t-1],p[t],p[t+1],1,e[t-1],e[t],e[t+1],1]; weight/bias grads = dy^T taps (ft_linear_bwd_weight) */
 int ft_cond_taps(const float* pitch, const float* energy, float* taps, int B, int T, void* stream);
 
@@ -147,18 +153,20 @@ int ft_masked_l1_bwd(const float* x, const float* target, const long* lens, cons
                      const float* grad_out, float factor, float* dx, int B, int C, int T, void* stream);
 
 /* ---- nn.GRU(bidirectional, batch_first), h0 = 0 (common_layers.py:89,123 ; forward_tacotron.py:24,37) - */
-/* xp[B,T,2*3H] = x W_ih^T + b_ih (dir 0 | dir 1); out[B,T,2H]; gates[B,T,2,4H] = (r,z,n,W_hn h+b_hn) or NULL */
+/* ALL recurrence buffers are TIME-major: xp[T,B,2*3H] = x W_ih^T + b_ih (dir 0 | dir 1); out[T,B,2H];
+ * gates[T,B,2,4H] = (r,z,n,W_hn h+b_hn) or NULL */
 int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
                float* out, float* gates, int B, int T, int H, void* stream);
-/* BPTT: whhT = W_hh^T [H,3H]; dxp / dhp [B,T,2*3H] = d(pre-activations) wrt input / hidden projections;
- * carry [B,2,H] scratch.  Weight grads follow from ft_linear_bwd_weight on dxp / dhp. */
+/* BPTT: dout[T,B,2H]; whhT = W_hh^T [H,3H]; dxp / dhp [T,B,2*3H] = d(pre-activations) wrt input / hidden
+ * projections; carry [B,2,H] scratch.  Weight grads follow from ft_linear_bwd_weight on dxp / dhp. */
 int ft_gru_bwd(const float* dout, const float* out, const float* gates, const float* whhT_f, const float* whhT_r,
                float* dxp, float* dhp, float* carry, int B, int T, int H, void* stream);
 
 /* ---- pack_padded_sequence -> nn.LSTM(bidirectional) -> pad_packed_sequence (forward_tacotron.py:96-99,147-152)
  * lens (int64 [B], device) or NULL = run over the padded length (generate path, :224).  Item b is processed
- * over exactly lens[b] frames in both directions; out_raw / cstate [B,T,2H] are ZERO at t >= lens[b];
- * ft_fill_padded then writes the padding_value the reference's unpack inserts. xp includes b_ih; b_hh added here. */
+ * over exactly lens[b] frames in both directions; out_raw / cstate [T,B,2H] (time-major, like xp / gates /
+ * dgates) are ZERO at t >= lens[b]; ft_fill_padded converts to batch-major [B,T,2H] and writes the
+ * padding_value the reference's unpack inserts (lens NULL: plain layout change). xp includes b_ih; b_hh added here. */
 int ft_lstm_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
                 const long* lens, float* out_raw, float* cstate, float* gates, int B, int T, int H, void* stream);
 int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, const float* gates,
@@ -166,6 +174,8 @@ int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, co
                 int H, void* stream);
 int ft_fill_padded(const float* raw, const long* lens, float* out, int B, int T, int C, float pad, void* stream);
 int ft_mask_rows(const float* src, const long* lens, float* dst, int B, int T, int C, void* stream);
+/* [B,T,C] -> [T,B,C] (dst_time_major = 1) or back (0) */
+int ft_bt_transpose(const float* src, float* dst, int B, int T, int C, int dst_time_major, void* stream);
 
 /* ---- clip_grad_norm_ + torch.optim.Adam (trainer/forward_trainer.py:95-99 ; train_forward.py:76) ------ */
 /* over FLAT fp32 buffers (all parameters back to back, 16-B aligned).  coef_and_norm[0] = pre_scale *

@@ -172,3 +172,39 @@ def test_length_regulator_all_zero(H):
     assert int(total.max()) == 0
     y = H.lr_expand(torch.randn(2, 3, 4, device='cuda'), cum, 0)
     assert tuple(y.shape) == (2, 0, 4)
+
+
+def test_linear_time_major_layouts(H):
+    """GEMMs read / write the recurrences' time-major [T,B,*] buffers without a transposition pass."""
+    from forwardtacotron_amd.hip import linear_bwd_weight_raw
+    g = torch.Generator().manual_seed(9)
+    B, T, I, O = 5, 13, 12, 7
+    x = torch.randn(B, T, I, generator=g); w = torch.randn(O, I, generator=g); b = torch.randn(O, generator=g)
+    ref = x.double() @ w.double().t() + b.double()                      # [B,T,O]
+    x_tm = x.transpose(0, 1).contiguous()
+    assert rel_err(H.linear_fwd(dev(x), dev(w), dev(b), y_tm_B=B), ref.transpose(0, 1)) < 2e-6
+    assert rel_err(H.linear_fwd(dev(x_tm), dev(w), dev(b), x_tm_B=B), ref) < 2e-6
+    assert rel_err(H.linear_fwd(dev(x_tm), dev(w), dev(b), x_tm_B=B, y_tm_B=B), ref.transpose(0, 1)) < 2e-6
+    assert rel_err(H.linear_multi_fwd(dev(x), [dev(w), dev(w)], [dev(b), None], y_tm_B=B)[..., :O],
+                   ref.transpose(0, 1)) < 2e-6
+    dy = torch.randn(B, T, O, generator=g)
+    dref = dy.double() @ w.double()
+    dy_tm = dy.transpose(0, 1).contiguous()
+    assert rel_err(H.linear_bwd_data(dev(dy_tm), dev(w), dy_tm_B=B), dref) < 2e-6
+    assert rel_err(H.linear_bwd_data(dev(dy), dev(w), dx_tm_B=B), dref.transpose(0, 1)) < 2e-6
+    assert tuple(H.bt_transpose(dev(x), True).shape) == (T, B, I)
+    assert torch.equal(H.bt_transpose(H.bt_transpose(dev(x), True), False).cpu(), x)
+    for dy_tm_f, x_tm_f, shift in [(True, False, 0), (False, True, 0), (True, True, -1), (True, True, 1)]:
+        xs = torch.zeros_like(x)
+        if shift == -1:
+            xs[:, 1:] = x[:, :-1]
+        elif shift == 1:
+            xs[:, :-1] = x[:, 1:]
+        else:
+            xs = x
+        wref = dy.reshape(-1, O).double().t() @ xs.reshape(-1, I).double()
+        dyd = dev(dy_tm if dy_tm_f else dy); xd = dev(x_tm if x_tm_f else x)
+        dw = torch.empty(O, I, device='cuda')
+        linear_bwd_weight_raw(dyd.data_ptr(), O, xd.data_ptr(), I, dw, B * T, I, O, B=B, T=T, x_shift=shift,
+                              dy_tm=dy_tm_f, x_tm=x_tm_f)
+        assert rel_err(dw, wref) < 2e-6, (dy_tm_f, x_tm_f, shift)
