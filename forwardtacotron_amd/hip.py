@@ -36,8 +36,9 @@ _workspaces = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (safe: every kernel runs on the current stream, in order)."""
-    key = (torch.device(device).index or 0)
+    """Grow-only scratch buffer per (device, stream): kernels of one stream run in order, so they can share
+    it; concurrent streams (the predictors' side stream) get their own."""
+    key = (torch.device(device).index or 0, _stream())
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -348,12 +349,11 @@ def embedding_bwd(idx: torch.Tensor, dout: torch.Tensor, V: int,
     share one id tensor (main + three predictors) build the one-hot matrix once."""
     _chk(idx, 'idx', torch.int64); _chk(dout, 'dout')
     C = dout.shape[-1]
-    key = (idx.data_ptr(), idx.numel(), V)
+    key = (idx.data_ptr(), idx.numel(), V, _stream())          # per stream: no cross-stream sharing
     oh = onehot_cache.get(key) if onehot_cache is not None else None
     if oh is None:
         oh = onehot(idx, V)
         if onehot_cache is not None:
-            onehot_cache.clear()
             onehot_cache[key] = oh
     dw = torch.empty(V, C, device=dout.device, dtype=dout.dtype)
     linear_bwd_weight_raw(_p(oh), V, _p(dout), C, dw, idx.numel(), C, V)

@@ -318,15 +318,34 @@ class ForwardTacotron(nn.Module):
             self.step += 1
             self._bump_batchnorm_counters()
 
-        dur_hat = self.dur_pred(x).squeeze(-1)
-        pitch_hat = self.pitch_pred(x).transpose(1, 2)
-        energy_hat = self.energy_pred(x).transpose(1, 2)
+        # The three predictors are independent of the trunk (forward_tacotron.py:129-131 vs :133-159) and
+        # their 128-step recurrences are latency-bound, so they run on a side HIP stream concurrently with the
+        # trunk; autograd replays each backward node on the stream of its forward, so the overlap also holds
+        # in backward.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dur_hat = self.dur_pred(x).squeeze(-1)
+            pitch_hat = self.pitch_pred(x).transpose(1, 2)
+            energy_hat = self.energy_pred(x).transpose(1, 2)
 
         mel_cl, post_cl = self._trunk(x, dur, pitch, energy, mel_lens.to(device=x.device, dtype=torch.long))
         Tout = mel.size(2)
         x_post = ops.TransposePadFn.apply(post_cl, Tout, self.padding_value)
         x_mel = ops.TransposePadFn.apply(mel_cl, Tout, self.padding_value)
+        main.wait_stream(side)
+        for t in (dur_hat, pitch_hat, energy_hat):
+            t.record_stream(main)
         return {'mel': x_mel, 'mel_post': x_post, 'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat}
+
+    def _side_stream(self, device) -> 'torch.cuda.Stream':
+        key = torch.device(device).index or 0
+        if not hasattr(self, '_streams'):
+            self._streams = {}
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
 
     def generate(self, x: torch.Tensor, alpha=1.0,
                  pitch_function: Callable[[torch.Tensor], torch.Tensor] = lambda x: x,

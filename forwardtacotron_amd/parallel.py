@@ -113,14 +113,17 @@ class BucketedAllReduce:
         self.launched = [False] * len(self.buckets)
         self.works = []
         self.armed = False
+        self.streams = set()
         if self.world > 1:
             for j, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(j))
 
     def _make_hook(self, j: int):
-        def hook(_p):
+        def hook(p):
             if not self.armed:
                 return
+            if p.is_cuda:                       # gradients may be produced on several streams (side stream
+                self.streams.add(torch.cuda.current_stream(p.device))   # of the predictors)
             b = self.param_bucket[j]
             self.pending[b] -= 1
             if self.pending[b] == 0:
@@ -132,6 +135,11 @@ class BucketedAllReduce:
             return
         lo, hi = self.buckets[b]
         self.launched[b] = True
+        if self.flat.grad.is_cuda:
+            cur = torch.cuda.current_stream(self.flat.grad.device)
+            for s in self.streams:              # the collective must see every producer stream's work
+                if s != cur:
+                    cur.wait_stream(s)
         self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
                                           async_op=True))
 
