@@ -137,6 +137,8 @@ def main():
     else:
         tot_frm, tot_tok = float(n_frm), float(n_tok)
     loss = float(out['loss'])
+    from forwardtacotron_amd import hip as _hip
+    _hip.check_rnn_status()            # raises if a persistent recurrence hit its spin bound
 
     if rank == 0:
         ms = dt / args.steps * 1e3

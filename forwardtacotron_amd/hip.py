@@ -456,13 +456,41 @@ def masked_l1_bwd(x, target, lens, inv, grad_out: Optional[torch.Tensor], factor
 # recurrences
 # ---------------------------------------------------------------------------------------------------
 # All recurrence buffers are TIME-major: xp [T,B,2*G*H], out / cstate [T,B,2H], gates [T,B,2,4H].
+_rnn_ws = {}          # (device, stream, gates, B, H) -> workspace of the persistent recurrence kernels
+_rnn_ws_used = []     # workspaces handed to a kernel since the last check_rnn_status()
+
+
+def _rnn_workspace(gates: int, B: int, H: int, device):
+    nbytes = _lib.query('ft_rnn_workspace', gates, B, H)
+    if nbytes == 0:
+        return None, 0
+    key = (torch.device(device).index or 0, _stream(), gates, B, H)
+    ws = _rnn_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _rnn_ws[key] = ws
+    if not any(w is ws for w in _rnn_ws_used):
+        _rnn_ws_used.append(ws)
+    return ws, nbytes
+
+
+def check_rnn_status() -> None:
+    """Synchronises and raises if any persistent recurrence launched since the last check timed out
+    (tests, smoke and bench call this; a training loop can call it every N steps)."""
+    used = list(_rnn_ws_used)
+    _rnn_ws_used.clear()
+    for ws in used:
+        _lib.call('ft_rnn_status', _p(ws), _stream())
+
+
 def gru_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool):
     _chk(xp, 'xp')
     T, B, _ = xp.shape
     out = torch.empty(T, B, 2 * H, device=xp.device, dtype=xp.dtype)
     gates = torch.empty(T, B, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
+    ws, nb = _rnn_workspace(3, B, H, xp.device)
     _lib.call('ft_gru_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(out), _p(gates), B, T, H,
-              _stream())
+              _p(ws), nb, _stream())
     return out, gates
 
 
@@ -472,8 +500,9 @@ def gru_bwd(dout, out, gates, whhT_f, whhT_r, H: int):
     dxp = torch.empty(T, B, 6 * H, device=out.device, dtype=out.dtype)
     dhp = torch.empty(T, B, 6 * H, device=out.device, dtype=out.dtype)
     carry = torch.empty(B, 2, H, device=out.device, dtype=out.dtype)
+    ws, nb = _rnn_workspace(3, B, H, out.device)
     _lib.call('ft_gru_bwd', _p(dout), _p(out), _p(gates), _p(whhT_f), _p(whhT_r), _p(dxp), _p(dhp), _p(carry), B, T,
-              H, _stream())
+              H, _p(ws), nb, _stream())
     return dxp, dhp
 
 
@@ -483,8 +512,9 @@ def lstm_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, lens: Optional[torch.Tensor], H: in
     raw = torch.empty(T, B, 2 * H, device=xp.device, dtype=xp.dtype)
     cst = torch.empty(T, B, 2 * H, device=xp.device, dtype=xp.dtype)
     gates = torch.empty(T, B, 2, 4 * H, device=xp.device, dtype=xp.dtype) if save_gates else None
+    ws, nb = _rnn_workspace(4, B, H, xp.device)
     _lib.call('ft_lstm_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(lens), _p(raw), _p(cst),
-              _p(gates), B, T, H, _stream())
+              _p(gates), B, T, H, _p(ws), nb, _stream())
     return raw, cst, gates
 
 
@@ -493,8 +523,9 @@ def lstm_bwd(dout, raw, cst, gates, whhT_f, whhT_r, lens: Optional[torch.Tensor]
     T, B, _ = raw.shape
     dg = torch.empty(T, B, 8 * H, device=raw.device, dtype=raw.dtype)
     carry = torch.empty(B, 2, H, device=raw.device, dtype=raw.dtype)
+    ws, nb = _rnn_workspace(4, B, H, raw.device)
     _lib.call('ft_lstm_bwd', _p(dout), _p(raw), _p(cst), _p(gates), _p(whhT_f), _p(whhT_r), _p(lens), _p(dg),
-              _p(carry), B, T, H, _stream())
+              _p(carry), B, T, H, _p(ws), nb, _stream())
     return dg
 
 

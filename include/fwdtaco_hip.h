@@ -155,12 +155,23 @@ int ft_masked_l1_bwd(const float* x, const float* target, const long* lens, cons
 /* ---- nn.GRU(bidirectional, batch_first), h0 = 0 (common_layers.py:89,123 ; forward_tacotron.py:24,37) - */
 /* ALL recurrence buffers are TIME-major: xp[T,B,2*3H] = x W_ih^T + b_ih (dir 0 | dir 1); out[T,B,2H];
  * gates[T,B,2,4H] = (r,z,n,W_hn h+b_hn) or NULL */
+/* `workspace` (ft_rnn_workspace(gates,B,H) bytes, may be NULL) enables the PERSISTENT form: one launch runs all T
+ * steps with W_hh resident in registers and h exchanged between workgroups inside the kernel (bounded spins).
+ * It is used when H % 16 == 0, the grid is co-resident per the occupancy query and FT_RNN_PERSISTENT != 0;
+ * otherwise one kernel per timestep is launched.  The first 4 bytes of the workspace are a status word
+ * (non-zero = a workgroup timed out); ft_rnn_status() synchronises the stream and reads it. */
+size_t ft_rnn_workspace(int gates, int B, int H);
+int ft_rnn_status(const void* workspace, void* stream);
+/* runtime override of FT_RNN_PERSISTENT (1 = allow the persistent form); returns the previous setting */
+int ft_rnn_set_persistent(int enabled);
 int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
-               float* out, float* gates, int B, int T, int H, void* stream);
+               float* out, float* gates, int B, int T, int H, void* workspace, size_t workspace_bytes,
+               void* stream);
 /* BPTT: dout[T,B,2H]; whhT = W_hh^T [H,3H]; dxp / dhp [T,B,2*3H] = d(pre-activations) wrt input / hidden
  * projections; carry [B,2,H] scratch.  Weight grads follow from ft_linear_bwd_weight on dxp / dhp. */
 int ft_gru_bwd(const float* dout, const float* out, const float* gates, const float* whhT_f, const float* whhT_r,
-               float* dxp, float* dhp, float* carry, int B, int T, int H, void* stream);
+               float* dxp, float* dhp, float* carry, int B, int T, int H, void* workspace, size_t workspace_bytes,
+               void* stream);
 
 /* ---- pack_padded_sequence -> nn.LSTM(bidirectional) -> pad_packed_sequence (forward_tacotron.py:96-99,147-152)
  * lens (int64 [B], device) or NULL = run over the padded length (generate path, :224).  Item b is processed
@@ -168,10 +179,11 @@ int ft_gru_bwd(const float* dout, const float* out, const float* gates, const fl
  * dgates) are ZERO at t >= lens[b]; ft_fill_padded converts to batch-major [B,T,2H] and writes the
  * padding_value the reference's unpack inserts (lens NULL: plain layout change). xp includes b_ih; b_hh added here. */
 int ft_lstm_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
-                const long* lens, float* out_raw, float* cstate, float* gates, int B, int T, int H, void* stream);
+                const long* lens, float* out_raw, float* cstate, float* gates, int B, int T, int H,
+                void* workspace, size_t workspace_bytes, void* stream);
 int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, const float* gates,
                 const float* whhT_f, const float* whhT_r, const long* lens, float* dgates, float* carry, int B, int T,
-                int H, void* stream);
+                int H, void* workspace, size_t workspace_bytes, void* stream);
 int ft_fill_padded(const float* raw, const long* lens, float* out, int B, int T, int C, float pad, void* stream);
 int ft_mask_rows(const float* src, const long* lens, float* dst, int B, int T, int C, void* stream);
 /* [B,T,C] -> [T,B,C] (dst_time_major = 1) or back (0) */

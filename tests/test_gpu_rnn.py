@@ -1,0 +1,126 @@
+"""GPU parity of the recurrences at MFMA-friendly widths (H % 16 == 0), where the PERSISTENT kernels run:
+persistent vs per-step kernels (same reduction order; differences are FMA-contraction noise) and both vs the CPU oracle,
+forward and BPTT, GRU and packed / unpacked LSTM, ragged lengths, B not a multiple of 16."""
+import pytest
+import torch
+
+from helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _set_persistent(flag):
+    from forwardtacotron_amd import _lib
+    return _lib.lib().ft_rnn_set_persistent(int(flag))
+
+
+def _params(G, I, Hh, g):
+    P = {}
+    for sfx in ('', '_reverse'):
+        P['weight_ih_l0' + sfx] = torch.randn(G * Hh, I, generator=g) * 0.3
+        P['weight_hh_l0' + sfx] = torch.randn(G * Hh, Hh, generator=g) * 0.3
+        P['bias_ih_l0' + sfx] = torch.randn(G * Hh, generator=g) * 0.1
+        P['bias_hh_l0' + sfx] = torch.randn(G * Hh, generator=g) * 0.1
+    return P
+
+
+@pytest.mark.parametrize('B,T,I,Hh', [(32, 23, 24, 64), (19, 17, 16, 32), (5, 9, 8, 16), (33, 12, 32, 128)])
+def test_gru_persistent_vs_step_vs_oracle(B, T, I, Hh):
+    from forwardtacotron_amd import model, hip
+    from oracle import ft_oracle as O
+    g = torch.Generator().manual_seed(B * 7 + Hh)
+    P = _params(3, I, Hh, g)
+    x = torch.randn(B, T, I, generator=g)
+    w = torch.randn(B, T, 2 * Hh, generator=g)
+    res = {}
+    for mode in (1, 0):
+        old = _set_persistent(mode)
+        try:
+            m = model.GRU(I, Hh)
+            m.load_state_dict(P)
+            m = m.cuda()
+            xg = x.cuda().requires_grad_(True)
+            y = m(xg)
+            (y * w.cuda()).sum().backward()
+            hip.check_rnn_status()
+            res[mode] = (y.detach().cpu(), xg.grad.cpu(), {k: getattr(m, k).grad.cpu() for k in P})
+        finally:
+            _set_persistent(old)
+    assert maxdiff(res[1][0], res[0][0]) < 2e-6, 'persistent forward differs from the per-step kernels'
+    assert maxdiff(res[1][1], res[0][1]) < 3e-5
+    xo = x.double().requires_grad_(True)
+    Po = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    yo = O.bigru(xo, Po, '')
+    (yo * w.double()).sum().backward()
+    assert maxdiff(res[1][0], yo.detach()) < 2e-5
+    assert maxdiff(res[1][1], xo.grad) < 1e-4
+    for k in P:
+        assert maxdiff(res[1][2][k], Po[k].grad) < 2e-4, k
+
+
+@pytest.mark.parametrize('B,T,I,Hh,packed', [(32, 21, 32, 64, True), (18, 15, 16, 32, True), (7, 11, 16, 16, False),
+                                             (32, 9, 64, 128, True)])
+def test_lstm_persistent_vs_step_vs_oracle(B, T, I, Hh, packed):
+    from forwardtacotron_amd import model, hip
+    from oracle import ft_oracle as O
+    g = torch.Generator().manual_seed(B * 3 + Hh)
+    P = _params(4, I, Hh, g)
+    x = torch.randn(B, T, I, generator=g)
+    w = torch.randn(B, T, 2 * Hh, generator=g)
+    lens = None
+    if packed:
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        lens[0] = T
+        lens[-1] = 1
+    res = {}
+    for mode in (1, 0):
+        old = _set_persistent(mode)
+        try:
+            m = model.LSTM(I, Hh)
+            m.load_state_dict(P)
+            m = m.cuda()
+            xg = x.cuda().requires_grad_(True)
+            y = m(xg, lens.cuda() if packed else None, -11.5129)
+            (y * w.cuda()).sum().backward()
+            hip.check_rnn_status()
+            res[mode] = (y.detach().cpu(), xg.grad.cpu(), {k: getattr(m, k).grad.cpu() for k in P})
+        finally:
+            _set_persistent(old)
+    assert maxdiff(res[1][0], res[0][0]) < 2e-6, 'persistent forward differs from the per-step kernels'
+    assert maxdiff(res[1][1], res[0][1]) < 3e-5
+    xo = x.double().requires_grad_(True)
+    Po = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    yo = O.bilstm(xo, lens, Po, '')
+    (yo * w.double()).sum().backward()
+    assert maxdiff(res[1][0], yo.detach()) < 2e-5
+    assert maxdiff(res[1][1], xo.grad) < 1e-4
+    for k in P:
+        assert maxdiff(res[1][2][k], Po[k].grad) < 2e-4, k
+
+
+def test_full_width_lstm_long_sequence_persistent_equals_step():
+    """BASELINE shape (B=32, H=512, T=841): the persistent kernels must reproduce the per-step kernels
+    to rounding noise over the whole sequence (property check: the oracle is too slow at this size)."""
+    from forwardtacotron_amd import hip as H
+    g = torch.Generator().manual_seed(1)
+    B, T, Hh = 32, 841, 512
+    xp = (torch.randn(T, B, 8 * Hh, generator=g) * 0.5).cuda()
+    whh = [(torch.randn(4 * Hh, Hh, generator=g) * 0.04).cuda() for _ in range(2)]
+    bhh = [(torch.randn(4 * Hh, generator=g) * 0.1).cuda() for _ in range(2)]
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0] = T
+    lens = lens.cuda()
+    outs = {}
+    for mode in (1, 0):
+        old = _set_persistent(mode)
+        try:
+            raw, cst, gates = H.lstm_fwd(xp, whh[0], whh[1], bhh[0], bhh[1], lens, Hh, True)
+            dout = torch.ones_like(raw) * 0.01
+            dg = H.lstm_bwd(dout, raw, cst, gates, H.transpose2d(whh[0]), H.transpose2d(whh[1]), lens, Hh)
+            H.check_rnn_status()
+            outs[mode] = (raw.cpu(), cst.cpu(), dg.cpu())
+        finally:
+            _set_persistent(old)
+    assert maxdiff(outs[1][0], outs[0][0]) < 1e-5 and maxdiff(outs[1][1], outs[0][1]) < 1e-4
+    assert torch.isfinite(outs[1][2]).all()
+    assert maxdiff(outs[1][2], outs[0][2]) < 1e-5
