@@ -31,8 +31,17 @@ __device__ __forceinline__ float4 ld4(const float* p, int remaining, bool vec) {
   return v;
 }
 
+// branch-free 16-B load: an invalid lane reads a safe address and its value is replaced by zeros with a
+// select (no exec-mask branches in the staging code)
+__device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, bool ok) {
+  const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
+  return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // ---------------------------------------------------------------------------------------------
-template <int TM, int TN, bool BNC>
+// FAST: every task has 16-B aligned operands, K % 4 == 0 (and N % 4 == 0 for the NN form): staging uses
+// ld4_sel only.  The generic form predicates every element (odd sizes, unaligned views).
+template <int TM, int TN, bool BNC, bool FAST>
 __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
   const FtGemmTask& T = batch.t[blockIdx.z];
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -40,8 +49,10 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
   constexpr int LDB = BNC ? BN + 4 : BN + 1;
   constexpr int PA = BM / 32;                 // float4 per thread for A
   constexpr int PB = BN / 32;                 // float4 per thread for B
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  // two LDS stages: stage c+1 is written while stage c is multiplied -> ONE barrier per K-stage, and the
+  // staging instructions issue in the shadow of the 64-cycle MFMAs
+  constexpr int STAGE = BK * LDA + BK * LDB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (m0 >= T.M || n0 >= T.N) return;
@@ -74,14 +85,16 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
       int ts = a_t[p] + shift;
       bool ok = a_ok[p] && ts >= 0 && ts < T.amap.Tvalid;
       const float* ptr = T.A + (a_base[p] + (long)ts * T.amap.tstride) * T.lda + k;
-      ra[p] = ld4(ptr, ok ? T.K - k : 0, T.a_vec);
+      if constexpr (FAST) ra[p] = ld4_sel(ptr, T.A, ok && k < T.K);
+      else ra[p] = ld4(ptr, ok ? T.K - k : 0, T.a_vec);
     }
     const float* Bj = T.B + (long)j * T.b_tap_stride;
     if constexpr (!BNC) {
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
         int n = n0 + rr + 32 * p;
-        rb[p] = ld4(Bj + (long)n * T.ldb + k, n < T.N ? T.K - k : 0, T.b_vec);
+        if constexpr (FAST) rb[p] = ld4_sel(Bj + (long)n * T.ldb + k, Bj, n < T.N && k < T.K);
+        else rb[p] = ld4(Bj + (long)n * T.ldb + k, n < T.N ? T.K - k : 0, T.b_vec);
       }
     } else {
       constexpr int NQ = BN / 4;              // float4 per k-row
@@ -91,11 +104,14 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
       for (int p = 0; p < PB; ++p) {
         int kk = k0 + kr + KR * p;
         int n = n0 + 4 * nq;
-        rb[p] = ld4(Bj + (long)kk * T.ldb + n, kk < T.K ? T.N - n : 0, T.b_vec);
+        if constexpr (FAST) rb[p] = ld4_sel(Bj + (long)kk * T.ldb + n, Bj, n < T.N && kk < T.K);
+        else rb[p] = ld4(Bj + (long)kk * T.ldb + n, kk < T.K ? T.N - n : 0, T.b_vec);
       }
     }
   };
-  auto store_stage = [&]() {
+  auto store_stage = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BK * LDA;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       int m = rr + 32 * p;
@@ -135,12 +151,17 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   load_stage(0);
+  store_stage(0);
+  if (nch > 1) load_stage(1);
+  __syncthreads();
   for (int c = 0; c < nch; ++c) {
-    store_stage();
-    __syncthreads();
-    if (c + 1 < nch) load_stage(c + 1);
-    const float* ap = As + half * LDA + wm * 32 * TM + l31;
-    const float* bp = Bs + half * LDB + wn * 32 * TN + l31;
+    const int cur = c & 1;
+    if (c + 1 < nch) {
+      store_stage(cur ^ 1);                  // stage c+1 (its registers were loaded one iteration ago)
+      if (c + 2 < nch) load_stage(c + 2);
+    }
+    const float* ap = smem + cur * STAGE + half * LDA + wm * 32 * TM + l31;
+    const float* bp = smem + cur * STAGE + BK * LDA + half * LDB + wn * 32 * TN + l31;
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
       float a[TM], b[TN];
@@ -171,8 +192,11 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
         if (row >= T.M) continue;
-        const int cb = row / T.cmap.Tlog;
-        const long crow = (long)cb * T.cmap.bstride + (long)(row - cb * T.cmap.Tlog) * T.cmap.tstride;
+        long crow = row;
+        if (T.cmap.bstride != 0) {            // non-identity output layout (time-major); identity skips the division
+          const int cb = row / T.cmap.Tlog;
+          crow = (long)cb * T.cmap.bstride + (long)(row - cb * T.cmap.Tlog) * T.cmap.tstride;
+        }
         float* cp = T.C + crow * T.ldc + col;
         float v = acc[i][j][e] + bv;
         if (T.relu) v = fmaxf(v, 0.f);
@@ -185,15 +209,15 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
 
 // ---------------------------------------------------------------------------------------------
 // TN: slab[z][m][n] = sum_{r in slice} A[map_a(r)][m] * B[map_b,tap(r)][n] ; z = tap*S + s
-template <int TM, int TN>
+template <int TM, int TN, bool FAST>
 __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* slab, int S, int rows_per_split) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int PA = BM / 32, PB = BN / 32;
   constexpr int AQ = BM / 4, AR = 256 / AQ;   // float4 per k-row, k-rows per pass
   constexpr int BQ = BN / 4, BR = 256 / BQ;
-  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+  constexpr int STAGE = BK * LDA + BK * LDB;    // two LDS stages, one barrier per K-stage (see rows kernel)
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int tap = blockIdx.z / S, s = blockIdx.z - tap * S;
@@ -214,8 +238,9 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       int ts = r - b * T.amap.Tlog + ashift;
       bool ok = r < r_end && ts >= 0 && ts < T.amap.Tvalid;
       int m = m0 + 4 * aq;
-      ra[p] = ld4(T.A + ((long)b * T.amap.bstride + (long)ts * T.amap.tstride) * T.lda + m, ok ? T.M - m : 0,
-                  T.a_vec);
+      const float* ptr = T.A + ((long)b * T.amap.bstride + (long)ts * T.amap.tstride) * T.lda + m;
+      if constexpr (FAST) ra[p] = ld4_sel(ptr, T.A, ok && m < T.M);
+      else ra[p] = ld4(ptr, ok ? T.M - m : 0, T.a_vec);
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
@@ -224,11 +249,14 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       int ts = r - b * T.bmap.Tlog + bshift;
       bool ok = r < r_end && ts >= 0 && ts < T.bmap.Tvalid;
       int n = n0 + 4 * bq;
-      rb[p] = ld4(T.B + ((long)b * T.bmap.bstride + (long)ts * T.bmap.tstride) * T.ldb + n, ok ? T.N - n : 0,
-                  T.b_vec);
+      const float* ptr = T.B + ((long)b * T.bmap.bstride + (long)ts * T.bmap.tstride) * T.ldb + n;
+      if constexpr (FAST) rb[p] = ld4_sel(ptr, T.B, ok && n < T.N);
+      else rb[p] = ld4(ptr, ok ? T.N - n : 0, T.b_vec);
     }
   };
-  auto store_stage = [&]() {
+  auto store_stage = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BK * LDA;
 #pragma unroll
     for (int p = 0; p < PA; ++p) *reinterpret_cast<float4*>(&As[(ar + AR * p) * LDA + 4 * aq]) = ra[p];
 #pragma unroll
@@ -248,12 +276,17 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
 
   if (r_begin < r_end) {
     load_stage(r_begin);
-    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
-      store_stage();
-      __syncthreads();
-      if (r0 + BK < r_end) load_stage(r0 + BK);
-      const float* ap = As + half * LDA + wm * 32 * TM + l31;
-      const float* bp = Bs + half * LDB + wn * 32 * TN + l31;
+    store_stage(0);
+    if (r_begin + BK < r_end) load_stage(r_begin + BK);
+    __syncthreads();
+    int cur = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += BK, cur ^= 1) {
+      if (r0 + BK < r_end) {
+        store_stage(cur ^ 1);
+        if (r0 + 2 * BK < r_end) load_stage(r0 + 2 * BK);
+      }
+      const float* ap = smem + cur * STAGE + half * LDA + wm * 32 * TM + l31;
+      const float* bp = smem + cur * STAGE + BK * LDA + half * LDB + wn * 32 * TN + l31;
 #pragma unroll
       for (int ks = 0; ks < BK / 2; ++ks) {
         float a[TM], b[TN];
@@ -355,17 +388,26 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   const int bm = big ? 128 : 64;
   dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), ntasks);
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_rows: grid too large");
-  if (big) {
-    if (b_ncontig)
-      hipLaunchKernelGGL((ft_gemm_rows_kernel<2, 2, true>), grid, dim3(256), 0, stream, *batch);
-    else
-      hipLaunchKernelGGL((ft_gemm_rows_kernel<2, 2, false>), grid, dim3(256), 0, stream, *batch);
-  } else {
-    if (b_ncontig)
-      hipLaunchKernelGGL((ft_gemm_rows_kernel<1, 1, true>), grid, dim3(256), 0, stream, *batch);
-    else
-      hipLaunchKernelGGL((ft_gemm_rows_kernel<1, 1, false>), grid, dim3(256), 0, stream, *batch);
+  bool fast = true;
+  for (int i = 0; i < ntasks; ++i) {
+    const FtGemmTask& t = batch->t[i];
+    fast = fast && t.a_vec && t.b_vec && (t.K % 4 == 0) && (!b_ncontig || t.N % 4 == 0);
   }
+#define FT_ROWS_LAUNCH(TM_, BNC_)                                                                              \
+  do {                                                                                                         \
+    if (fast)                                                                                                  \
+      hipLaunchKernelGGL((ft_gemm_rows_kernel<TM_, TM_, BNC_, true>), grid, dim3(256), 0, stream, *batch);     \
+    else                                                                                                       \
+      hipLaunchKernelGGL((ft_gemm_rows_kernel<TM_, TM_, BNC_, false>), grid, dim3(256), 0, stream, *batch);    \
+  } while (0)
+  if (big) {
+    if (b_ncontig) FT_ROWS_LAUNCH(2, true);
+    else FT_ROWS_LAUNCH(2, false);
+  } else {
+    if (b_ncontig) FT_ROWS_LAUNCH(1, true);
+    else FT_ROWS_LAUNCH(1, false);
+  }
+#undef FT_ROWS_LAUNCH
   return ft_check_launch("gemm_rows");
 }
 
@@ -383,10 +425,14 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   const int bm = 64 * p.tm;
   dim3 grid(ft_cdiv(t.M, bm), ft_cdiv(t.N, bm), p.S * t.taps);
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_tn: grid too large");
-  if (p.tm == 2)
-    hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
-  else
-    hipLaunchKernelGGL((ft_gemm_tn_kernel<1, 1>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
+  const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
+  if (p.tm == 2) {
+    if (fast) hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
+    else hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
+  } else {
+    if (fast) hipLaunchKernelGGL((ft_gemm_tn_kernel<1, 1, true>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
+    else hipLaunchKernelGGL((ft_gemm_tn_kernel<1, 1, false>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
+  }
   int rc = ft_check_launch("gemm_tn");
   if (rc) return rc;
   long total = (long)t.taps * t.M * t.N;
