@@ -31,6 +31,46 @@ __device__ __forceinline__ float4 ld4(const float* p, int remaining, bool vec) {
   return v;
 }
 
+// One K-stage of MFMAs from the K-major LDS tiles.  The operand fragments of k-pair ks+1 are requested
+// BEFORE the MFMAs of k-pair ks are issued (explicit register double buffering): an MFMA occupies the
+// matrix pipe for 64 cycles and the wave issues in order, so reads placed after the MFMA block would expose
+// the LDS latency once per k-pair.
+template <int TM, int TN, int LDA, int LDB>
+__device__ __forceinline__ void mfma_stage(const float* ap, const float* bp, f32x16 (&acc)[TM][TN]) {
+  float a0[TM], b0[TN], a1[TM], b1[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a0[i] = ap[32 * i];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b0[j] = bp[32 * j];
+#pragma unroll
+  for (int ks = 0; ks < BK / 2; ks += 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a1[i] = ap[2 * (ks + 1) * LDA + 32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b1[j] = bp[2 * (ks + 1) * LDB + 32 * j];
+    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the MFMA block (the scheduler sinks it)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 < BK / 2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a0[i] = ap[2 * (ks + 2) * LDA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b0[j] = bp[2 * (ks + 2) * LDB + 32 * j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // branch-free 16-B load: an invalid lane reads a safe address and its value is replaced by zeros with a
 // select (no exec-mask branches in the staging code)
 __device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, bool ok) {
@@ -162,19 +202,7 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
     }
     const float* ap = smem + cur * STAGE + half * LDA + wm * 32 * TM + l31;
     const float* bp = smem + cur * STAGE + BK * LDA + half * LDB + wn * 32 * TN + l31;
-#pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = ap[2 * ks * LDA + 32 * i];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = bp[2 * ks * LDB + 32 * j];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+    mfma_stage<TM, TN, LDA, LDB>(ap, bp, acc);
     __syncthreads();
   }
 
@@ -287,19 +315,7 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       }
       const float* ap = smem + cur * STAGE + half * LDA + wm * 32 * TM + l31;
       const float* bp = smem + cur * STAGE + BK * LDA + half * LDB + wn * 32 * TN + l31;
-#pragma unroll
-      for (int ks = 0; ks < BK / 2; ++ks) {
-        float a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = ap[2 * ks * LDA + 32 * i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = bp[2 * ks * LDB + 32 * j];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
+      mfma_stage<TM, TN, LDA, LDB>(ap, bp, acc);
       __syncthreads();
     }
   }

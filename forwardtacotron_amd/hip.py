@@ -251,14 +251,17 @@ def bn_train_fwd(y: torch.Tensor, gamma, beta, running_mean, running_var, Tout: 
     return out, mean, rstd
 
 
-def bn_bwd(dout: torch.Tensor, y: torch.Tensor, gamma, mean, rstd, group: int, relu: bool):
-    """-> (dy [B,Tbuf,C], dgamma [C], dbeta [C])"""
+def bn_bwd(dout: torch.Tensor, y: torch.Tensor, gamma, mean, rstd, group: int, relu: bool,
+           dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None):
+    """-> (dy [B,Tbuf,C], dgamma [C], dbeta [C]); dgamma / dbeta may be caller-provided output buffers"""
     _chk(dout, 'dout'); _chk(y, 'y')
     B, Tbuf, C = y.shape
     Tout = dout.shape[1]
     dy = torch.empty_like(y)
-    dgamma = torch.empty(C, device=y.device, dtype=y.dtype)
-    dbeta = torch.empty(C, device=y.device, dtype=y.dtype)
+    if dgamma is None:
+        dgamma = torch.empty(C, device=y.device, dtype=y.dtype)
+    if dbeta is None:
+        dbeta = torch.empty(C, device=y.device, dtype=y.dtype)
     nbytes = _lib.query('ft_bn_workspace', B, Tbuf, C)
     ws = workspace(nbytes, y.device)
     _lib.call('ft_bn_bwd', _p(dout), _p(y), _p(gamma), _p(mean), _p(rstd), _p(dy), _p(dgamma), _p(dbeta), B, Tbuf,
@@ -344,7 +347,7 @@ def onehot(idx: torch.Tensor, V: int) -> torch.Tensor:
 
 
 def embedding_bwd(idx: torch.Tensor, dout: torch.Tensor, V: int,
-                  onehot_cache: Optional[dict] = None) -> torch.Tensor:
+                  onehot_cache: Optional[dict] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[V,C] = onehot(idx)^T @ dout (TN MFMA GEMM).  onehot_cache lets the four embedding tables that
     share one id tensor (main + three predictors) build the one-hot matrix once."""
     _chk(idx, 'idx', torch.int64); _chk(dout, 'dout')
@@ -355,7 +358,7 @@ def embedding_bwd(idx: torch.Tensor, dout: torch.Tensor, V: int,
         oh = onehot(idx, V)
         if onehot_cache is not None:
             onehot_cache[key] = oh
-    dw = torch.empty(V, C, device=dout.device, dtype=dout.dtype)
+    dw = out if out is not None else torch.empty(V, C, device=dout.device, dtype=dout.dtype)
     linear_bwd_weight_raw(_p(oh), V, _p(dout), C, dw, idx.numel(), C, V)
     return dw
 

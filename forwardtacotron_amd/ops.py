@@ -2,7 +2,8 @@
 
 Each op is a torch.autograd.Function whose forward AND backward are sequences of hand-written gfx950
 kernels reached through the C ABI (forwardtacotron_amd.hip).  Activations are channels-last [B,T,C]
-throughout.  torch only owns the memory, the stream and the autograd graph.
+throughout; recurrence outputs are time-major [T,B,C].  torch only owns the memory, the streams and
+the autograd graph.
 """
 from typing import List, Optional
 
@@ -19,23 +20,103 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------
+# Gradient sink (installed by trainer.TrainStep; absent = plain autograd semantics).
+#
+# Every parameter of the model receives exactly one gradient contribution per backward pass, so the
+# weight-gradient kernels can write STRAIGHT into the trainer's flat gradient buffer (no temporary, no
+# AccumulateGrad add) and the backward returns None for that input.  Weight gradients are off the
+# critical data-gradient chain, so with a sink the GEMM-shaped ones are issued on a second HIP stream and
+# overlap the latency-bound persistent recurrences; the trainer joins that stream before the optimiser.
+# ---------------------------------------------------------------------------------------------------
+class GradSink:
+    def __init__(self, views, stream=None, on_write=None):
+        self.views = views              # {param.data_ptr(): (index, grad view tensor)}
+        self.written = set()
+        self.stream = stream            # side stream for weight-gradient GEMMs (None: current stream)
+        self.on_write = on_write        # callback(index) -> lets the bucketed all-reduce count arrivals
+
+    def begin_step(self):
+        self.written.clear()
+
+
+_SINK: Optional[GradSink] = None
+
+
+def set_grad_sink(sink: Optional[GradSink]) -> None:
+    global _SINK
+    _SINK = sink
+
+
+def _sink_view(w: torch.Tensor):
+    """(index, view) of w's slot in the flat gradient buffer if a sink is installed and the slot is still
+    unwritten this step, else None."""
+    if _SINK is None:
+        return None
+    ent = _SINK.views.get(w.data_ptr())
+    if ent is None or ent[0] in _SINK.written:
+        return None
+    return ent
+
+
+def _sink_done(idx: int) -> None:
+    _SINK.written.add(idx)
+    if _SINK.on_write is not None:
+        _SINK.on_write(idx)
+
+
+def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
+    """Produces the gradient of parameter `w`: compute(out) must overwrite `out` (same shape as w).
+    Without a sink: returns a fresh tensor (autograd accumulates it).  With a sink: writes the flat-buffer
+    view (on the side stream when `heavy`) and returns None."""
+    ent = _sink_view(w)
+    if ent is None:
+        out = torch.empty_like(w)
+        compute(out)
+        return out
+    idx, view = ent
+    side = _SINK.stream if heavy else None
+    if side is None:
+        compute(view)
+    else:
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        for t in deps:                  # keep the operands' memory from being recycled under the side stream
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            compute(view)
+    _sink_done(idx)
+    return None
+
+
+def _emit_copy(w: torch.Tensor, value: torch.Tensor):
+    """Small vector gradients that a fused kernel already produced in `value`."""
+    ent = _sink_view(w)
+    if ent is None:
+        return value
+    ent[1].copy_(value.view_as(ent[1]))
+    _sink_done(ent[0])
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------
 class EmbeddingFn(Function):
     """nn.Embedding (forward_tacotron.py:18,73)."""
-
     _onehot_cache: dict = {}
 
     @staticmethod
     def forward(ctx, idx, w):
         idx = _c(idx)
-        ctx.save_for_backward(idx)
-        ctx.V = w.shape[0]
+        ctx.save_for_backward(idx, w)
         EmbeddingFn._onehot_cache.clear()      # ids may have changed in place since the last step
         return H.embedding_fwd(idx, w)
 
     @staticmethod
     def backward(ctx, dout):
-        (idx,) = ctx.saved_tensors
-        return None, H.embedding_bwd(idx, _c(dout), ctx.V, EmbeddingFn._onehot_cache)
+        idx, w = ctx.saved_tensors
+        dout = _c(dout)
+        V = w.shape[0]
+        dw = _emit(w, lambda out: H.embedding_bwd(idx, dout, V, EmbeddingFn._onehot_cache, out=out), (dout, idx))
+        return None, dw
 
 
 class LinearFn(Function):
@@ -46,26 +127,30 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, x_tm_B=0):
         x = _c(x)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, b)
         ctx.tmB = int(x_tm_B)
         return H.linear_fwd(x, w, b, x_tm_B=ctx.tmB, y_tm_B=0)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         dy = _c(dy)
         tmB = ctx.tmB
         dx = H.linear_bwd_data(dy, w, dy_tm_B=0, dx_tm_B=tmB) if ctx.needs_input_grad[0] else None
-        if tmB:
-            out_f, in_f = w.shape
-            rows = x.numel() // in_f
-            dw = torch.empty_like(w)
-            H.linear_bwd_weight_raw(dy.data_ptr(), out_f, x.data_ptr(), in_f, dw, rows, in_f, out_f, B=tmB,
-                                    T=rows // tmB, dy_tm=False, x_tm=True)
-        else:
-            dw = H.linear_bwd_weight(dy, x)
-        db = H.colsum(dy) if ctx.has_bias else None
+        out_f, in_f = w.shape
+        rows = x.numel() // in_f
+
+        def wgrad(out):
+            if tmB:
+                H.linear_bwd_weight_raw(dy.data_ptr(), out_f, x.data_ptr(), in_f, out, rows, in_f, out_f, B=tmB,
+                                        T=rows // tmB, dy_tm=False, x_tm=True)
+            else:
+                H.linear_bwd_weight_raw(dy.data_ptr(), out_f, x.data_ptr(), in_f, out, rows, in_f, out_f)
+
+        dw = _emit(w, wgrad, (dy, x))
+        db = None
+        if b is not None:
+            db = _emit(b, lambda out: H.colsum_raw(dy.data_ptr(), out_f, out, rows, out_f), heavy=False)
         return dx, dw, db, None
 
 
@@ -97,26 +182,32 @@ class BatchNormConvFn(Function):
         y = H.conv1d_fwd(x, wp, relu=relu, Tout=Tbuf)
         out, mean, rstd = H.bn_train_fwd(y, gamma, beta, running_mean, running_var, Tout=T, group=0,
                                          residual=_c(residual) if residual is not None else None)
-        ctx.save_for_backward(x, wp, y, gamma, mean, rstd)
+        ctx.save_for_backward(x, wp, y, gamma, mean, rstd, w, beta)
         ctx.relu = relu
-        ctx.wshape = w.shape
         ctx.has_res = residual is not None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, wp, y, gamma, mean, rstd = ctx.saved_tensors
+        x, wp, y, gamma, mean, rstd, w, beta = ctx.saved_tensors
         dout = _c(dout)
         B, T, Cin = x.shape
-        Cout, _, k = ctx.wshape
+        Cout, _, k = w.shape
         Tbuf = y.shape[1]
-        dy, dgamma, dbeta = H.bn_bwd(dout, y, gamma, mean, rstd, group=0, relu=ctx.relu)
+        eg, eb = _sink_view(gamma), _sink_view(beta)
+        dy, dgamma, dbeta = H.bn_bwd(dout, y, gamma, mean, rstd, group=0, relu=ctx.relu,
+                                     dgamma=eg[1] if eg else None, dbeta=eb[1] if eb else None)
+        if eg:
+            _sink_done(eg[0])
+            dgamma = None
+        if eb:
+            _sink_done(eb[0])
+            dbeta = None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             H.conv1d_bwd_data_raw(dy.data_ptr(), Cout, wp, dx, B, T, Tbuf, Tbuf, False)
-        dw = torch.empty(ctx.wshape, device=x.device, dtype=x.dtype)
-        H.conv1d_bwd_weight_raw(dy.data_ptr(), Cout, x, dw, Tbuf, Tbuf)
+        dw = _emit(w, lambda out: H.conv1d_bwd_weight_raw(dy.data_ptr(), Cout, x, out, Tbuf, Tbuf), (dy, x))
         dres = dout if ctx.has_res else None
         return dx, dw, dgamma, dbeta, dres, None, None, None
 
@@ -142,14 +233,16 @@ class ConvBankFn(Function):
         ybank = H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T + 1)
         z, mean, rstd = H.bn_train_fwd(ybank, gamma, beta, running_mean, running_var, Tout=T, group=C)
         out = H.maxpool2_fwd(z)
-        ctx.save_for_backward(x, wp_all, ybank, z, gamma, mean, rstd)
+        ctx.save_for_backward(x, wp_all, ybank, z, gamma, mean, rstd, *params)
         ctx.K, ctx.C = K, C
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, wp_all, ybank, z, gamma, mean, rstd = ctx.saved_tensors
+        x, wp_all, ybank, z, gamma, mean, rstd = ctx.saved_tensors[:7]
+        params = ctx.saved_tensors[7:]
         K, C = ctx.K, ctx.C
+        ws, gs, bs = params[:K], params[K:2 * K], params[2 * K:3 * K]
         B, T, Cin = x.shape
         dz = H.maxpool2_bwd(_c(dout), z)
         dy, dgamma, dbeta = H.bn_bwd(dz, ybank, gamma, mean, rstd, group=C, relu=True)
@@ -164,12 +257,11 @@ class ConvBankFn(Function):
             wp = wp_all[off:off + n].view(k, C, Cin)
             if dx is not None:
                 H.conv1d_bwd_data_raw(dptr, K * C, wp, dx, B, T, T + 1, Tvalid, i > 0)
-            dw = torch.empty(C, Cin, k, device=x.device, dtype=x.dtype)
-            H.conv1d_bwd_weight_raw(dptr, K * C, x, dw, T + 1, Tvalid)
-            dws.append(dw)
+            dws.append(_emit(ws[i], lambda out, dptr=dptr, Tvalid=Tvalid: H.conv1d_bwd_weight_raw(
+                dptr, K * C, x, out, T + 1, Tvalid), (dy, x)))
             off += n
-        dgs = [dgamma[i * C:(i + 1) * C] for i in range(K)]
-        dbs = [dbeta[i * C:(i + 1) * C] for i in range(K)]
+        dgs = [_emit_copy(gs[i], dgamma[i * C:(i + 1) * C]) for i in range(K)]
+        dbs = [_emit_copy(bs[i], dbeta[i * C:(i + 1) * C]) for i in range(K)]
         return (dx, None, None, None, None, None, *dws, *dgs, *dbs)
 
 
@@ -204,49 +296,53 @@ class HighwayFn(Function):
     def forward(ctx, x, w1, b1, w2, b2):
         x = _c(x)
         x12 = H.linear_multi_fwd(x, [w1, w2], [b1, b2])
-        ctx.save_for_backward(x, x12, w1, w2)
+        ctx.save_for_backward(x, x12, w1, w2, b1, b2)
         return H.highway_gate_fwd(x12, x)
 
     @staticmethod
     def backward(ctx, dout):
-        x, x12, w1, w2 = ctx.saved_tensors
+        x, x12, w1, w2, b1, b2 = ctx.saved_tensors
         C = x.shape[-1]
         rows = x.numel() // C
         d12, dx = H.highway_gate_bwd(_c(dout), x12, x)
         p = d12.data_ptr()
         H.linear_bwd_data_raw(p, 2 * C, w1, dx, rows, C, True)
         H.linear_bwd_data_raw(p + C * _F4, 2 * C, w2, dx, rows, C, True)
-        dw1 = torch.empty_like(w1)
-        dw2 = torch.empty_like(w2)
-        H.linear_bwd_weight_raw(p, 2 * C, x.data_ptr(), C, dw1, rows, C, C)
-        H.linear_bwd_weight_raw(p + C * _F4, 2 * C, x.data_ptr(), C, dw2, rows, C, C)
-        db = H.colsum(d12)
-        return dx, dw1, db[:C], dw2, db[C:]
+        dw1 = _emit(w1, lambda out: H.linear_bwd_weight_raw(p, 2 * C, x.data_ptr(), C, out, rows, C, C), (d12, x))
+        dw2 = _emit(w2, lambda out: H.linear_bwd_weight_raw(p + C * _F4, 2 * C, x.data_ptr(), C, out, rows, C, C),
+                    (d12, x))
+        db1 = _emit(b1, lambda out: H.colsum_raw(p, 2 * C, out, rows, C), heavy=False)
+        db2 = _emit(b2, lambda out: H.colsum_raw(p + C * _F4, 2 * C, out, rows, C), heavy=False)
+        return dx, dw1, db1, dw2, db2
 
 
 # ---------------------------------------------------------------------------------------------------
-def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, w_ih_f, w_ih_r, need_dx):
+def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx):
     """Shared tail of the GRU/LSTM backward: weight / bias / input gradients from the per-step
     pre-activation gradients (dxp wrt input projection, dhp wrt hidden projection).
-    x is batch-major [B,T,I]; dxp / dhp / hid are the recurrence's time-major [T,B,*] buffers."""
+    x is batch-major [B,T,I]; dxp / dhp / hid are the recurrence's time-major [T,B,*] buffers.
+    params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)."""
     B, T, I = x.shape
     rows = B * T
     GH = G * Hh
-    grads = []
+    grads: List[Optional[torch.Tensor]] = []
     dx = torch.empty_like(x) if need_dx else None
     dbx = H.colsum(dxp)                       # [2*G*H]
     dbh = dbx if dhp is dxp else H.colsum(dhp)
-    for d, w_ih in enumerate((w_ih_f, w_ih_r)):
+    for d in range(2):
+        w_ih, w_hh, b_ih, b_hh = params[4 * d:4 * d + 4]
         px = dxp.data_ptr() + d * GH * _F4
         ph = dhp.data_ptr() + d * GH * _F4
-        dw_ih = torch.empty(GH, I, device=x.device, dtype=x.dtype)
-        H.linear_bwd_weight_raw(px, 2 * GH, x.data_ptr(), I, dw_ih, rows, I, GH, B=B, T=T, dy_tm=True, x_tm=False)
-        dw_hh = torch.empty(GH, Hh, device=x.device, dtype=x.dtype)
-        H.linear_bwd_weight_raw(ph, 2 * GH, hid.data_ptr() + d * Hh * _F4, 2 * Hh, dw_hh, rows, Hh, GH, B=B, T=T,
-                                x_shift=-1 if d == 0 else 1, dy_tm=True, x_tm=True)
         if dx is not None:
             H.linear_bwd_data_raw(px, 2 * GH, w_ih, dx, rows, GH, d > 0, dy_tm_B=B, dx_tm_B=0)
-        grads.append((dw_ih, dw_hh, dbx[d * GH:(d + 1) * GH], dbh[d * GH:(d + 1) * GH]))
+        g_ih = _emit(w_ih, lambda out, px=px: H.linear_bwd_weight_raw(
+            px, 2 * GH, x.data_ptr(), I, out, rows, I, GH, B=B, T=T, dy_tm=True, x_tm=False), (dxp, x))
+        g_hh = _emit(w_hh, lambda out, ph=ph, d=d: H.linear_bwd_weight_raw(
+            ph, 2 * GH, hid.data_ptr() + d * Hh * _F4, 2 * Hh, out, rows, Hh, GH, B=B, T=T,
+            x_shift=-1 if d == 0 else 1, dy_tm=True, x_tm=True), (dhp, hid))
+        g_bi = _emit_copy(b_ih, dbx[d * GH:(d + 1) * GH])
+        g_bh = _emit_copy(b_hh, dbh[d * GH:(d + 1) * GH])
+        grads += [g_ih, g_hh, g_bi, g_bh]
     return dx, grads
 
 
@@ -262,17 +358,18 @@ class BiGRUFn(Function):
         xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
         out, gates = H.gru_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, Hh, save_gates=train)
         if train:
-            ctx.save_for_backward(x, out, gates, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+            ctx.save_for_backward(x, out, gates, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.Hh = Hh
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, out, gates, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
+        x, out, gates = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
         Hh = ctx.Hh
-        dxp, dhp = H.gru_bwd(_c(dout), out, gates, H.transpose2d(w_hh_f), H.transpose2d(w_hh_r), Hh)
-        dx, g = _rnn_param_grads(dxp, dhp, x, out, 3, Hh, w_ih_f, w_ih_r, ctx.needs_input_grad[0])
-        return (dx, g[0][0], g[0][1], g[0][2], g[0][3], g[1][0], g[1][1], g[1][2], g[1][3])
+        dxp, dhp = H.gru_bwd(_c(dout), out, gates, H.transpose2d(params[1]), H.transpose2d(params[5]), Hh)
+        dx, g = _rnn_param_grads(dxp, dhp, x, out, 3, Hh, params, ctx.needs_input_grad[0])
+        return (dx, *g)
 
 
 class BiLSTMFn(Function):
@@ -287,7 +384,8 @@ class BiLSTMFn(Function):
         xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
         raw, cst, gates = H.lstm_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens, Hh, save_gates=train)
         if train:
-            ctx.save_for_backward(x, raw, cst, gates, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens)
+            ctx.save_for_backward(x, raw, cst, gates, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
+                                  b_ih_r, b_hh_r)
         ctx.Hh = Hh
         ctx.has_lens = lens is not None
         # time-major raw states -> batch-major output, padding_value beyond each item's length
@@ -295,12 +393,13 @@ class BiLSTMFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, raw, cst, gates, w_ih_f, w_hh_f, w_ih_r, w_hh_r, lens = ctx.saved_tensors
+        x, raw, cst, gates, lens = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
         Hh = ctx.Hh
-        dg = H.lstm_bwd(H.bt_transpose(_c(dout), True), raw, cst, gates, H.transpose2d(w_hh_f),
-                        H.transpose2d(w_hh_r), lens if ctx.has_lens else None, Hh)
-        dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, w_ih_f, w_ih_r, ctx.needs_input_grad[0])
-        return (dx, None, None, g[0][0], g[0][1], g[0][2], g[0][3], g[1][0], g[1][1], g[1][2], g[1][3])
+        dg = H.lstm_bwd(H.bt_transpose(_c(dout), True), raw, cst, gates, H.transpose2d(params[1]),
+                        H.transpose2d(params[5]), lens if ctx.has_lens else None, Hh)
+        dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, params, ctx.needs_input_grad[0])
+        return (dx, None, None, *g)
 
 
 # ---------------------------------------------------------------------------------------------------

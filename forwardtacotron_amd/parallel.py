@@ -120,15 +120,20 @@ class BucketedAllReduce:
 
     def _make_hook(self, j: int):
         def hook(p):
-            if not self.armed:
-                return
-            if p.is_cuda:                       # gradients may be produced on several streams (side stream
-                self.streams.add(torch.cuda.current_stream(p.device))   # of the predictors)
-            b = self.param_bucket[j]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                self._launch(b)
+            self.notify(j)
         return hook
+
+    def notify(self, j: int) -> None:
+        """Gradient of parameter j is complete (called by the autograd hook, or by the gradient sink when the
+        backward kernels write the flat buffer directly)."""
+        if not self.armed or self.world <= 1:
+            return
+        if self.flat.grad.is_cuda:              # gradients may be produced on several streams
+            self.streams.add(torch.cuda.current_stream(self.flat.grad.device))
+        b = self.param_bucket[j]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
 
     def _launch(self, b: int) -> None:
         if self.launched[b]:

@@ -42,6 +42,11 @@ class TrainStep:
         self.coef = torch.zeros(2, device=dev, dtype=torch.float32)      # [clip coefficient, grad norm]
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = BucketedAllReduce(self.flat, process_group, bucket_bytes)
+        # weight gradients are written straight into the flat buffer, the GEMM-shaped ones on a side stream
+        self.wgrad_stream = torch.cuda.Stream(device=dev)
+        self.reducer.streams.add(self.wgrad_stream)
+        self.sink = ops.GradSink({p.data_ptr(): (i, p.grad) for i, p in enumerate(self.flat.params)},
+                                 stream=self.wgrad_stream, on_write=self.reducer.notify)
 
     # -- state for checkpoints: same content as torch.optim.Adam's (exp_avg / exp_avg_sq / step), flat
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -81,7 +86,13 @@ class TrainStep:
         L = self.losses(pred, batch, pitch_target, energy_target)
         self.flat.zero_grad()
         self.reducer.start()
-        L['loss'].backward()
+        self.sink.begin_step()
+        ops.set_grad_sink(self.sink)
+        try:
+            L['loss'].backward()
+        finally:
+            ops.set_grad_sink(None)
+        torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         self.reducer.finish()
         self.optimizer_step()
         out = {k: v.detach() for k, v in L.items()}
