@@ -153,6 +153,102 @@ __global__ void ft_cond_taps_kernel(const float* __restrict__ pitch, const float
   o[4] = t > 0 ? e[-1] : 0.f; o[5] = e[0]; o[6] = t + 1 < T ? e[1] : 0.f; o[7] = 1.f;
 }
 
+// ---- feature concat with a broadcast speaker embedding (multi_forward_tacotron.py:39-42,83-85,208-210) ----
+// out[b,t,:] = [ a[b,t,:Ca] | b2[b,t,:Cb] | semb[b,:S] ]   (a may be time-major [T,B,Ca])
+__global__ void ft_concat_cols_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b2, int Cb,
+                                      const float* __restrict__ semb, int S, float* __restrict__ out, int B, int T,
+                                      int a_time_major) {
+  const int C = Ca + Cb + S;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * T * C;
+  if (i >= total) return;
+  long row = i / C;
+  int c = (int)(i - row * C);
+  int b = (int)(row / T), t = (int)(row - (long)b * T);
+  float v;
+  if (c < Ca) v = a[(a_time_major ? ((long)t * B + b) : row) * Ca + c];
+  else if (c < Ca + Cb) v = b2[row * Cb + (c - Ca)];
+  else v = semb[(long)b * S + (c - Ca - Cb)];
+  out[i] = v;
+}
+// dst[b,t,:C] = src[(b,t)*ld + col0 + :C]   (dst optionally time-major [T,B,C])
+__global__ void ft_slice_cols_kernel(const float* __restrict__ src, long ld, int col0, int C,
+                                     float* __restrict__ dst, int B, int T, int dst_time_major) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)B * T * C;
+  if (i >= total) return;
+  long row = i / C;
+  int c = (int)(i - row * C);
+  long srow = row;
+  if (dst_time_major) {
+    int t = (int)(row / B), b = (int)(row - (long)t * B);
+    srow = (long)b * T + t;
+  }
+  dst[i] = src[srow * ld + col0 + c];
+}
+
+// ---- CrossEntropyLoss(ignore_index) over logits [rows, K] (multi_forward_trainer.py:34,88) ----------------
+// loss = mean over rows with target != ignore of (logsumexp(logits) - logits[target])
+__global__ __launch_bounds__(256) void ft_ce_partial_kernel(const float* __restrict__ logits,
+                                                            const long* __restrict__ target, long rows, int K,
+                                                            long ignore, double* __restrict__ partial) {
+  __shared__ double red[2][4];
+  double s = 0.0, n = 0.0;
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    long tg = target[r];
+    if (tg == ignore || tg < 0 || tg >= K) continue;
+    const float* l = logits + r * K;
+    float mx = l[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, l[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(l[k] - mx);
+    s += (double)(logf(se) + mx - l[tg]);
+    n += 1.0;
+  }
+  s = ft_wave_sum_d(s);
+  n = ft_wave_sum_d(n);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s;
+    red[1][threadIdx.x >> 6] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ void ft_ce_finalize_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ loss,
+                                      float* __restrict__ inv_count) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0, n = 0.0;
+  for (int i = 0; i < nblocks; ++i) {
+    s += partial[2 * i];
+    n += partial[2 * i + 1];
+  }
+  *loss = (float)(s / n);              // n == 0 -> NaN, like torch
+  *inv_count = (float)(1.0 / n);
+}
+// dlogits[r,k] = (softmax_k - [k == target]) * inv_count * g   (0 for ignored rows)
+__global__ void ft_ce_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ target,
+                                 const float* __restrict__ inv_count, const float* __restrict__ gout,
+                                 float* __restrict__ dlogits, long rows, int K, long ignore) {
+  long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  long tg = target[r];
+  const float* l = logits + r * K;
+  float* d = dlogits + r * K;
+  if (tg == ignore || tg < 0 || tg >= K) {
+    for (int k = 0; k < K; ++k) d[k] = 0.f;
+    return;
+  }
+  float mx = l[0];
+  for (int k = 1; k < K; ++k) mx = fmaxf(mx, l[k]);
+  float se = 0.f;
+  for (int k = 0; k < K; ++k) se += expf(l[k] - mx);
+  const float sc = inv_count[0] * (gout ? gout[0] : 1.f);
+  for (int k = 0; k < K; ++k) d[k] = (expf(l[k] - mx) / se - (k == tg ? 1.f : 0.f)) * sc;
+}
+
 // ---- [B,T,C] <-> [B,C,Tout] with padding (forward_tacotron.py:155,159,236-239) ---------------------
 // out[b,c,t] = t < T ? x[b,t,c] : pad   for t < Tout
 __global__ __launch_bounds__(256) void ft_transpose_pad_kernel(const float* __restrict__ x, float* __restrict__ out,
@@ -362,6 +458,48 @@ int ft_transpose_pad_bwd(const float* dout, float* dx, int B, int T, int C, int 
   hipLaunchKernelGGL(ft_transpose_pad_bwd_kernel, dim3(ft_cdiv(T, 32), ft_cdiv(C, 32), B), dim3(256), 0,
                      (hipStream_t)stream, dout, dx, T, C, Tout);
   return ft_check_launch("transpose_pad_bwd");
+}
+
+int ft_concat_cols(const float* a, int Ca, const float* b2, int Cb, const float* semb, int S, float* out, int B,
+                   int T, int a_time_major, void* stream) {
+  FT_REQUIRE(Ca >= 0 && Cb >= 0 && S >= 0 && (Cb == 0 || b2) && (S == 0 || semb), "concat_cols: bad arguments");
+  long total = (long)B * T * (Ca + Cb + S);
+  if (total <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_concat_cols_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a, Ca, b2,
+                     Cb, semb, S, out, B, T, a_time_major);
+  return ft_check_launch("concat_cols");
+}
+
+int ft_slice_cols(const float* src, long ld, int col0, int C, float* dst, int B, int T, int dst_time_major,
+                  void* stream) {
+  long total = (long)B * T * C;
+  if (total <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_slice_cols_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, src, ld, col0,
+                     C, dst, B, T, dst_time_major);
+  return ft_check_launch("slice_cols");
+}
+
+size_t ft_cross_entropy_workspace(void) { return 2 * 256 * sizeof(double); }
+
+int ft_cross_entropy_fwd(const float* logits, const long* target, long rows, int K, long ignore_index, float* loss,
+                         float* inv_count, void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(rows > 0 && K > 0, "cross_entropy_fwd: bad dims");
+  FT_REQUIRE(workspace && workspace_bytes >= ft_cross_entropy_workspace(), "cross_entropy_fwd: workspace too small");
+  int nb = ft_cdiv(rows, 256);
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(ft_ce_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, logits, target, rows, K,
+                     ignore_index, (double*)workspace);
+  hipLaunchKernelGGL(ft_ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, nb,
+                     loss, inv_count);
+  return ft_check_launch("cross_entropy_fwd");
+}
+
+int ft_cross_entropy_bwd(const float* logits, const long* target, const float* inv_count, const float* grad_out,
+                         float* dlogits, long rows, int K, long ignore_index, void* stream) {
+  if (rows <= 0) return FT_OK;
+  hipLaunchKernelGGL(ft_ce_bwd_kernel, dim3(ft_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, logits, target,
+                     inv_count, grad_out, dlogits, rows, K, ignore_index);
+  return ft_check_launch("cross_entropy_bwd");
 }
 
 size_t ft_masked_l1_workspace(void) { return 1024 * sizeof(double); }

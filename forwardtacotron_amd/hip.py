@@ -414,6 +414,48 @@ def cond_taps(pitch, energy) -> torch.Tensor:
     return taps
 
 
+def concat_cols(a: torch.Tensor, b2: Optional[torch.Tensor], semb: Optional[torch.Tensor], B: int, T: int,
+                a_time_major: bool = False) -> torch.Tensor:
+    """[a | b2 | broadcast(semb)] along the feature dim -> batch-major [B,T,Ca+Cb+S]"""
+    _chk(a, 'a')
+    Ca = a.shape[-1]
+    Cb = b2.shape[-1] if b2 is not None else 0
+    S = semb.shape[-1] if semb is not None else 0
+    out = torch.empty(B, T, Ca + Cb + S, device=a.device, dtype=a.dtype)
+    _lib.call('ft_concat_cols', _p(a), Ca, _p(b2), Cb, _p(semb), S, _p(out), B, T, int(a_time_major), _stream())
+    return out
+
+
+def slice_cols(src: torch.Tensor, col0: int, C: int, dst_time_major: bool = False) -> torch.Tensor:
+    """src batch-major [B,T,ld] -> src[..., col0:col0+C] as a contiguous [B,T,C] (or time-major [T,B,C])"""
+    _chk(src, 'src')
+    B, T, ld = src.shape
+    dst = torch.empty((T, B, C) if dst_time_major else (B, T, C), device=src.device, dtype=src.dtype)
+    _lib.call('ft_slice_cols', _p(src), ld, col0, C, _p(dst), B, T, int(dst_time_major), _stream())
+    return dst
+
+
+def cross_entropy_fwd(logits: torch.Tensor, target: torch.Tensor, ignore_index: int):
+    _chk(logits, 'logits'); _chk(target, 'target', torch.int64)
+    K = logits.shape[-1]
+    rows = logits.numel() // K
+    loss = torch.empty((), device=logits.device, dtype=logits.dtype)
+    inv = torch.empty(1, device=logits.device, dtype=logits.dtype)
+    ws = workspace(_lib.query('ft_cross_entropy_workspace'), logits.device)
+    _lib.call('ft_cross_entropy_fwd', _p(logits), _p(target), rows, K, ignore_index, _p(loss), _p(inv), _p(ws),
+              ws.numel(), _stream())
+    return loss, inv
+
+
+def cross_entropy_bwd(logits, target, inv, grad_out, ignore_index: int) -> torch.Tensor:
+    K = logits.shape[-1]
+    rows = logits.numel() // K
+    d = torch.empty_like(logits)
+    _lib.call('ft_cross_entropy_bwd', _p(logits), _p(target), _p(inv), _p(grad_out), _p(d), rows, K, ignore_index,
+              _stream())
+    return d
+
+
 def transpose_pad_fwd(x: torch.Tensor, Tout: int, pad: float) -> torch.Tensor:
     _chk(x, 'x')
     B, T, C = x.shape

@@ -482,3 +482,47 @@ class MaskedL1Fn(Function):
 
 def masked_l1(x, target, lens):
     return MaskedL1Fn.apply(x, target, lens)
+
+
+class ConcatColsFn(Function):
+    """torch.cat([a, b2, speaker_emb[:, None, :].repeat(1, T, 1)], dim=2)
+    (multi_forward_tacotron.py:39-42,83-85,208-210).  a may be a time-major recurrence output; the speaker
+    embedding is input data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, a, b2, semb, B, T, a_time_major):
+        a = _c(a)
+        ctx.Ca = a.shape[-1]
+        ctx.Cb = b2.shape[-1] if b2 is not None else 0
+        ctx.a_tm = bool(a_time_major)
+        return H.concat_cols(a, _c(b2) if b2 is not None else None, _c(semb) if semb is not None else None, B, T,
+                             ctx.a_tm)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _c(dout)
+        da = H.slice_cols(dout, 0, ctx.Ca, dst_time_major=ctx.a_tm) if ctx.needs_input_grad[0] else None
+        db = H.slice_cols(dout, ctx.Ca, ctx.Cb) if (ctx.Cb and ctx.needs_input_grad[1]) else None
+        return da, db, None, None, None, None
+
+
+class CrossEntropyFn(Function):
+    """nn.CrossEntropyLoss(ignore_index) on logits [..., K] and int64 targets [...]
+    (trainer/multi_forward_trainer.py:34,88; the reference transposes to [B,K,T] first, same reduction)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits, target = _c(logits), _c(target)
+        loss, inv = H.cross_entropy_fwd(logits, target, int(ignore_index))
+        ctx.save_for_backward(logits, target, inv)
+        ctx.ignore = int(ignore_index)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, inv = ctx.saved_tensors
+        return H.cross_entropy_bwd(logits, target, inv, _c(g).reshape(1).float(), ctx.ignore), None, None
+
+
+def cross_entropy(logits, target, ignore_index=0):
+    return CrossEntropyFn.apply(logits, target, ignore_index)

@@ -62,7 +62,13 @@ class TrainStep:
         pl = ops.masked_l1(pred['pitch'], pitch_target.unsqueeze(1), batch['x_len'])
         el = ops.masked_l1(pred['energy'], energy_target.unsqueeze(1), batch['x_len'])
         loss = m1 + m2 + c['dur_loss_factor'] * dl + c['pitch_loss_factor'] * pl + c['energy_loss_factor'] * el
-        return {'loss': loss, 'mel': m1, 'mel_post': m2, 'dur': dl, 'pitch': pl, 'energy': el}
+        out = {'mel': m1, 'mel_post': m2, 'dur': dl, 'pitch': pl, 'energy': el}
+        if 'pitch_cond' in pred:        # multispeaker: CrossEntropyLoss(ignore_index=0), multi_forward_trainer.py:34,88
+            ce = ops.cross_entropy(pred['pitch_cond'], batch['pitch_cond'], 0)
+            loss = loss + c.get('pitch_cond_loss_factor', 0.1) * ce
+            out['pitch_cond'] = ce
+        out['loss'] = loss
+        return out
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """batch: device tensors with the ForwardCollator layout (utils/dataset.py:239-263).  Returns the

@@ -139,6 +139,21 @@ int ft_cond_add_fwd(const float* x, const float* pitch, const float* energy, con
 /* taps[row][8] = [p[t-1],p[t],p[t+1],1,e[t-1],e[t],e[t+1],1]; weight/bias grads = dy^T taps (ft_linear_bwd_weight) */
 int ft_cond_taps(const float* pitch, const float* energy, float* taps, int B, int T, void* stream);
 
+/* ---- multispeaker plumbing (models/multi_forward_tacotron.py:39-42,83-85,208-210) ---------------------- */
+/* out[b,t,:] = [ a[b,t,:Ca] | b2[b,t,:Cb] | semb[b,:S] ]  (speaker embedding broadcast over t); a may be a
+ * time-major [T,B,Ca] recurrence output; b2 / semb optional (Cb = 0 / S = 0) */
+int ft_concat_cols(const float* a, int Ca, const float* b2, int Cb, const float* semb, int S, float* out, int B,
+                   int T, int a_time_major, void* stream);
+/* dst[b,t,:C] = src[(b,t)*ld + col0 + :C] ; dst optionally time-major (backward of the concat) */
+int ft_slice_cols(const float* src, long ld, int col0, int C, float* dst, int B, int T, int dst_time_major,
+                  void* stream);
+/* nn.CrossEntropyLoss(ignore_index) on logits[rows,K] / int64 target[rows] (trainer/multi_forward_trainer.py:34,88) */
+size_t ft_cross_entropy_workspace(void);
+int ft_cross_entropy_fwd(const float* logits, const long* target, long rows, int K, long ignore_index, float* loss,
+                         float* inv_count, void* workspace, size_t workspace_bytes, void* stream);
+int ft_cross_entropy_bwd(const float* logits, const long* target, const float* inv_count, const float* grad_out,
+                         float* dlogits, long rows, int K, long ignore_index, void* stream);
+
 /* ---- output layout + ForwardTacotron._pad (forward_tacotron.py:155,159,161-162,236-239) ---------------- */
 /* out[b,c,t] = t < T ? x[b,t,c] : pad, t < Tout   ([B,T,C] -> [B,C,Tout]) ; bwd is the masked transpose back */
 int ft_transpose_pad_fwd(const float* x, float* out, int B, int T, int C, int Tout, float pad, void* stream);

@@ -424,6 +424,94 @@ def train_step(P: Dict[str, Tensor], opt_state: Dict[str, Dict[str, Tensor]], ba
 
 
 # --------------------------------------------------------------------------- #
+# multispeaker variant  (models/multi_forward_tacotron.py, trainer/multi_forward_trainer.py)
+# --------------------------------------------------------------------------- #
+def _speaker_cat(parts: List[Tensor], semb: Tensor) -> Tensor:
+    """torch.cat([..., semb[:, None, :].repeat(1, T, 1)], dim=2)  (multi_forward_tacotron.py:39-42,83-85)."""
+    T = parts[0].shape[1]
+    return torch.cat(parts + [semb[:, None, :].repeat(1, T, 1)], dim=2)
+
+
+def multi_series_predictor(x_idx, semb, P, prefix, training, alpha=1.0, new_buffers=None, x_cond=None):
+    """SeriesPredictor / ConditionalSeriesPredictor.forward (multi_forward_tacotron.py:35-50, 76-93)."""
+    parts = [embedding(x_idx, P[prefix + 'embedding.weight'])]
+    if x_cond is not None:
+        parts.append(embedding(x_cond, P[prefix + 'pitch_cond_embedding.weight']))
+    x = _speaker_cat(parts, semb).transpose(1, 2)
+    for i in range(3):
+        x = batchnorm_conv(x, P, f'{prefix}convs.{i}.', True, training, new_buffers)
+    x = bigru(x.transpose(1, 2), P, prefix + 'rnn.')
+    return linear(x, P[prefix + 'lin.weight'], P[prefix + 'lin.bias']) / alpha
+
+
+def multi_forward(P, batch, cfg, training):
+    """MultiForwardTacotron.forward (multi_forward_tacotron.py:186-241), dropout = 0."""
+    nb: Dict[str, Tensor] = {}
+    x_idx, mel, dur, semb, mel_lens = batch['x'], batch['mel'], batch['dur'], batch['speaker_emb'], batch['mel_len']
+    pitch, energy, pitch_cond = batch['pitch'].unsqueeze(1), batch['energy'].unsqueeze(1), batch['pitch_cond']
+    if training:
+        nb['step'] = P['step'] + 1
+    pc_hat = multi_series_predictor(x_idx, semb, P, 'pitch_cond_pred.', training, 1.0, nb)
+    dur_hat = multi_series_predictor(x_idx, semb, P, 'dur_pred.', training, 1.0, nb, pitch_cond).squeeze(-1)
+    pitch_hat = multi_series_predictor(x_idx, semb, P, 'pitch_pred.', training, 1.0, nb, pitch_cond).transpose(1, 2)
+    energy_hat = multi_series_predictor(x_idx, semb, P, 'energy_pred.', training, 1.0, nb).transpose(1, 2)
+    x = embedding(x_idx, P['embedding.weight']).transpose(1, 2)
+    x = cbhg(x, P, 'prenet.', cfg['prenet_k'], cfg['prenet_num_highways'], training, nb)
+    x = _speaker_cat([x], semb)
+    x = x + conv1d(pitch, P['pitch_proj.weight'], P['pitch_proj.bias']).transpose(1, 2) * cfg['pitch_strength']
+    x = x + conv1d(energy, P['energy_proj.weight'], P['energy_proj.bias']).transpose(1, 2) * cfg['energy_strength']
+    x = length_regulate(x, dur)
+    pv = cfg.get('padding_value', PAD_VALUE)
+    x = bilstm(x, mel_lens, P, 'lstm.', pv)
+    x = linear(x, P['lin.weight'], P['lin.bias']).transpose(1, 2)
+    xp = cbhg(x, P, 'postnet.', cfg['postnet_k'], cfg['postnet_num_highways'], training, nb)
+    xp = linear(xp, P['post_proj.weight']).transpose(1, 2)
+    out = {'mel': pad_to(x, mel.shape[2], pv), 'mel_post': pad_to(xp, mel.shape[2], pv), 'dur': dur_hat,
+           'pitch': pitch_hat, 'energy': energy_hat, 'pitch_cond': pc_hat}
+    return out, nb
+
+
+def cross_entropy(logits: Tensor, target: Tensor, ignore_index: int = 0) -> Tensor:
+    """nn.CrossEntropyLoss(ignore_index=0) (multi_forward_trainer.py:34,88) on logits [...,K], target [...]."""
+    K = logits.shape[-1]
+    l2 = logits.reshape(-1, K)
+    t = target.reshape(-1)
+    keep = t != ignore_index
+    lse = torch.logsumexp(l2, dim=1)
+    picked = l2.gather(1, t.clamp(0, K - 1).unsqueeze(1)).squeeze(1)
+    return ((lse - picked) * keep.to(l2.dtype)).sum() / keep.sum()
+
+
+def multi_train_step(P, opt_state, batch, cfg, train_cfg, lr, step_count):
+    """multi_forward_trainer.py:73-99 with dropout = 0."""
+    leaf = {k: (v.detach().clone().requires_grad_(True) if is_param(k) else v) for k, v in P.items()}
+    b = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    pitch_target = b['pitch'].detach().clone()
+    energy_target = b['energy'].detach().clone()
+    pred, new_buf = multi_forward(leaf, b, cfg, training=True)
+    L = losses(pred, b, pitch_target, energy_target, train_cfg)
+    ce = cross_entropy(pred['pitch_cond'], b['pitch_cond'], 0)
+    L['pitch_cond'] = ce
+    L['loss'] = L['loss'] + train_cfg['pitch_cond_loss_factor'] * ce
+    names = [k for k in leaf if is_param(k)]
+    gl = torch.autograd.grad(L['loss'], [leaf[k] for k in names], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(names, gl)}
+    clipped, gnorm = clip_grad_norm(grads, train_cfg['clip_grad_norm'])
+    new_P = dict(P)
+    new_opt = {}
+    for k in names:
+        st = opt_state.get(k) or {'m': torch.zeros_like(P[k]), 'v': torch.zeros_like(P[k])}
+        p, m, v = adam_step(P[k], clipped[k], st['m'], st['v'], step_count, lr)
+        new_P[k] = p
+        new_opt[k] = {'m': m, 'v': v}
+    for k, v in new_buf.items():
+        new_P[k] = v
+    info = {'losses': {k: v.detach() for k, v in L.items()}, 'grads': grads, 'grad_norm': gnorm,
+            'pred': {k: v.detach() for k, v in pred.items()}}
+    return new_P, new_opt, info
+
+
+# --------------------------------------------------------------------------- #
 # synthetic LJSpeech-shaped batch  (SURVEY.md section 8d) -- shared by tests and bench
 # --------------------------------------------------------------------------- #
 def synthetic_batch(B: int = 32, Tmax: int = 128, n_mels: int = 80, num_chars: int = 135,

@@ -275,6 +275,87 @@ def make_layers():
     print('layers.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
 
 
+TINY_MULTI = dict(embed_dims=16, series_embed_dims=8, num_chars=135,
+                  durpred_conv_dims=16, durpred_rnn_dims=8, durpred_dropout=0.0,
+                  pitch_conv_dims=16, pitch_rnn_dims=12, pitch_dropout=0.0, pitch_strength=1.0,
+                  pitch_cond_conv_dims=12, pitch_cond_rnn_dims=8, pitch_cond_dropout=0.0,
+                  energy_conv_dims=16, energy_rnn_dims=8, energy_dropout=0.0, energy_strength=0.5,
+                  rnn_dims=20, prenet_dims=16, prenet_k=4, postnet_num_highways=2,
+                  prenet_dropout=0.0, postnet_dims=12, postnet_k=3, prenet_num_highways=2,
+                  postnet_dropout=0.0, n_mels=10, speaker_emb_dims=256, pitch_cond_emb_dims=4,
+                  pitch_cond_categorical_dims=3)
+
+
+def make_tiny_multi():
+    """MultiForwardTacotron (models/multi_forward_tacotron.py) + the multi trainer's loss
+    (trainer/multi_forward_trainer.py:73-99, restated here because the trainer module needs tensorboard)."""
+    from models.multi_forward_tacotron import MultiForwardTacotron
+    torch.manual_seed(4321)
+    g = torch.Generator().manual_seed(77)
+    model = MultiForwardTacotron(**TINY_MULTI)
+    randomize_bn(model, g)
+    batch = tiny_batch(g, TINY_MULTI['n_mels'])
+    batch['pitch_cond'] = ((batch['pitch'] != 0).long() + 1) * (batch['x'] > 0).long()
+    se = torch.randn(3, 256, generator=g)
+    batch['speaker_emb'] = se / se.norm(dim=1, keepdim=True)
+    out = {}
+    for k, v in model.state_dict().items():
+        out['sd/' + k] = v.clone().numpy()
+    for k, v in batch.items():
+        out['batch/' + k] = v.clone().numpy()
+    model.eval()
+    with torch.no_grad():
+        pred = model({k: v.clone() for k, v in batch.items()})
+    for k, v in pred.items():
+        out['eval/' + k] = v.numpy()
+    model.train()
+    optim = torch.optim.Adam(model.parameters())
+    lr = 1e-3
+    for gr in optim.param_groups:
+        gr['lr'] = lr
+    b = {k: v.clone() for k, v in batch.items()}
+    pitch_target = b['pitch'].detach().clone()
+    energy_target = b['energy'].detach().clone()
+    pred = model(b)
+    l1 = MaskedL1()
+    ce = torch.nn.CrossEntropyLoss(ignore_index=0)
+    m1 = l1(pred['mel'], b['mel'], b['mel_len'])
+    m2 = l1(pred['mel_post'], b['mel'], b['mel_len'])
+    dl = l1(pred['dur'].unsqueeze(1), b['dur'].unsqueeze(1), b['x_len'])
+    pl = l1(pred['pitch'], pitch_target.unsqueeze(1), b['x_len'])
+    el = l1(pred['energy'], energy_target.unsqueeze(1), b['x_len'])
+    pcl = ce(pred['pitch_cond'].transpose(1, 2), b['pitch_cond'])
+    loss = m1 + m2 + 0.1 * dl + 0.1 * pl + 0.1 * el + 0.1 * pcl
+    optim.zero_grad()
+    loss.backward()
+    for k, v in pred.items():
+        out['train/' + k] = v.detach().numpy()
+    out['loss/total'] = loss.detach().numpy()
+    out['loss/pitch_cond'] = pcl.detach().numpy()
+    for k, p in model.named_parameters():
+        out['grad/' + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).clone().numpy()
+    out['grad_norm'] = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0).numpy()
+    optim.step()
+    for k, v in model.state_dict().items():
+        out['sd_after/' + k] = v.clone().numpy()
+    out['lr'] = np.float64(lr)
+    model.eval()
+    x1 = torch.randint(1, 135, (1, 7), generator=g)
+    gen = model.generate(x1, batch['speaker_emb'][:1], alpha=1.1)
+    out['gen/x'] = x1.numpy()
+    for k, v in gen.items():
+        out['gen/' + k] = v.numpy()
+    for k, v in model.state_dict().items():
+        out['gen_sd/' + k] = v.clone().numpy()
+    np.savez_compressed(os.path.join(HERE, 'tiny_multi.npz'), **out)
+    print('tiny_multi.npz', sum(v.nbytes for v in out.values()) // 1024, 'KiB raw')
+
+
 if __name__ == '__main__':
-    make_tiny_model()
-    make_layers()
+    which = sys.argv[1:] or ['model', 'layers', 'multi']
+    if 'model' in which:
+        make_tiny_model()
+    if 'layers' in which:
+        make_layers()
+    if 'multi' in which:
+        make_tiny_multi()

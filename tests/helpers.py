@@ -56,3 +56,15 @@ def maxdiff(a, b):
     if a.numel() == 0:
         return 0.0
     return float((a - b).abs().max())
+
+TINY_MULTI = dict(embed_dims=16, series_embed_dims=8, num_chars=135,
+                  durpred_conv_dims=16, durpred_rnn_dims=8, durpred_dropout=0.0,
+                  pitch_conv_dims=16, pitch_rnn_dims=12, pitch_dropout=0.0, pitch_strength=1.0,
+                  pitch_cond_conv_dims=12, pitch_cond_rnn_dims=8, pitch_cond_dropout=0.0,
+                  energy_conv_dims=16, energy_rnn_dims=8, energy_dropout=0.0, energy_strength=0.5,
+                  rnn_dims=20, prenet_dims=16, prenet_k=4, postnet_num_highways=2,
+                  prenet_dropout=0.0, postnet_dims=12, postnet_k=3, prenet_num_highways=2,
+                  postnet_dropout=0.0, n_mels=10, speaker_emb_dims=256, pitch_cond_emb_dims=4,
+                  pitch_cond_categorical_dims=3)
+TRAIN_CFG_MULTI = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss_factor=0.1,
+                       pitch_cond_loss_factor=0.1, clip_grad_norm=1.0)

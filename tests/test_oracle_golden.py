@@ -140,3 +140,22 @@ def test_generate():
         for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
             assert out[k].shape == G[f'{tag}/{k}'].shape, (tag, k)
             assert maxdiff(out[k], G[f'{tag}/{k}']) < 2e-5, (tag, k)
+
+
+def test_tiny_multispeaker_model():
+    """MultiForwardTacotron restatement vs the imported reference (eval + full train step with CE loss)."""
+    from helpers import TINY_MULTI, TRAIN_CFG_MULTI
+    M = load_npz('tiny_multi.npz')
+    P = sub(M, 'sd/')
+    batch = sub(M, 'batch/')
+    pred, _ = O.multi_forward(P, {k: v.clone() for k, v in batch.items()}, TINY_MULTI, training=False)
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy', 'pitch_cond'):
+        assert maxdiff(pred[k], M['eval/' + k]) < 2e-5, k
+    newP, _, info = O.multi_train_step(P, {}, batch, TINY_MULTI, TRAIN_CFG_MULTI, float(M['lr']), 1)
+    assert abs(float(info['losses']['loss']) - float(M['loss/total'])) < 1e-5
+    assert abs(float(info['losses']['pitch_cond']) - float(M['loss/pitch_cond'])) < 1e-6
+    worst = max(maxdiff(g, M['grad/' + k]) for k, g in info['grads'].items())
+    assert worst < 1e-4, worst
+    for k, v in sub(M, 'sd_after/').items():
+        if v.dtype.is_floating_point:
+            assert maxdiff(newP[k], v) < 2e-5, k
