@@ -230,6 +230,82 @@ int ft_conv1d_bwd_weight(const float* dy, long lddy, const float* x, long ldx, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// Conv1d WITH bias (FFTBlock conv1/conv2, common_layers.py:161-164)
+int ft_conv1d_bias_fwd(const float* x, long ldx, const float* wp, const float* bias, float* y, long ldy, int B, int T,
+                       int Cin, int Cout, int k, int relu, void* stream) {
+  FT_REQUIRE(k >= 1 && (k % 2) == 1, "conv1d_bias_fwd: odd kernel sizes only");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  conv_fwd_task(b.t[0], x, ldx, wp, y, ldy, B, T, Cin, Cout, k, T, relu);
+  b.t[0].bias = bias;
+  return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// strided-batch GEMMs: instance z -> (z0, z1) = (z / nb1, z % nb1), X_z = X + z0*sX0 + z1*sX1
+static void set_batch(FtGemmTask& t, int nb0, int nb1, long sA0, long sA1, long sB0, long sB1, long sC0, long sC1) {
+  t.nz = nb0 * nb1; t.nz1 = nb1;
+  t.sA0 = sA0; t.sA1 = sA1; t.sB0 = sB0; t.sB1 = sB1; t.sC0 = sC0; t.sC1 = sC1;
+}
+
+int ft_bgemm_nt(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
+                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, void* stream) {
+  FT_REQUIRE(nb0 >= 1 && nb1 >= 1, "bgemm_nt: bad batch");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  FtGemmTask& t = b.t[0];
+  t.A = A; t.B = Bm; t.C = C;
+  t.lda = lda; t.ldb = ldb; t.ldc = ldc;
+  t.M = M; t.N = N; t.K = K; t.taps = 1;
+  t.amap = ft_rowmap_identity(M);
+  set_batch(t, nb0, nb1, sA0, sA1, sB0, sB1, sC0, sC1);
+  return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
+}
+
+int ft_bgemm_nn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
+                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, void* stream) {
+  FT_REQUIRE(nb0 >= 1 && nb1 >= 1, "bgemm_nn: bad batch");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  FtGemmTask& t = b.t[0];
+  t.A = A; t.B = Bm; t.C = C;
+  t.lda = lda; t.ldb = ldb; t.ldc = ldc;
+  t.M = M; t.N = N; t.K = K; t.taps = 1;
+  t.amap = ft_rowmap_identity(M);
+  set_batch(t, nb0, nb1, sA0, sA1, sB0, sB1, sC0, sC1);
+  return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
+}
+
+static FtGemmTNTask bgemm_tn_task(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0,
+                                  long sB1, float* C, long ldc, long sC0, long sC1, int M, int N, int R, int nb0,
+                                  int nb1) {
+  FtGemmTNTask t;
+  memset(&t, 0, sizeof(t));
+  t.A = A; t.B = Bm; t.dst = C;
+  t.lda = lda; t.ldb = ldb;
+  t.ldm = ldc; t.ldn = 1; t.ldj = 0;
+  t.M = M; t.N = N; t.R = R; t.taps = 1;
+  t.amap = ft_rowmap_identity(R);
+  t.bmap = ft_rowmap_identity(R);
+  t.nz = nb0 * nb1; t.nz1 = nb1;
+  t.sA0 = sA0; t.sA1 = sA1; t.sB0 = sB0; t.sB1 = sB1; t.sD0 = sC0; t.sD1 = sC1;
+  return t;
+}
+
+size_t ft_bgemm_tn_workspace(int M, int N, int R, int nb0, int nb1) {
+  FtGemmTNTask t = bgemm_tn_task(nullptr, M, 0, 0, nullptr, N, 0, 0, nullptr, N, 0, 0, M, N, R, nb0, nb1);
+  return ft_gemm_tn_workspace_floats(t) * sizeof(float);
+}
+
+int ft_bgemm_tn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
+                long ldc, long sC0, long sC1, int M, int N, int R, int nb0, int nb1, void* workspace,
+                size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(nb0 >= 1 && nb1 >= 1, "bgemm_tn: bad batch");
+  FtGemmTNTask t = bgemm_tn_task(A, lda, sA0, sA1, Bm, ldb, sB0, sB1, C, ldc, sC0, sC1, M, N, R, nb0, nb1);
+  return ft_launch_gemm_tn(t, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 int ft_lr_scan(float* dur, int B, int Tx, int* cum, int* total, void* stream) {
   return ft_lr_scan_impl(dur, B, Tx, cum, total, (hipStream_t)stream);
 }

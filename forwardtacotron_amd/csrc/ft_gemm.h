@@ -38,6 +38,10 @@ struct FtGemmTask {
   FtRowMap amap;
   FtRowMap cmap;        // output row permutation (Tlog/bstride/tstride only); identity by default
   int relu, accumulate, a_vec, b_vec;
+  // strided batch (attention: one GEMM per (batch item, head)); only for single-task launches.
+  // instance z = blockIdx.z -> (z0, z1) = (z / nz1, z % nz1); X += z0*sX0 + z1*sX1 (floats)
+  int nz, nz1;
+  long sA0, sA1, sB0, sB1, sC0, sC1;
 };
 #define FT_MAX_TASKS 16
 struct FtGemmBatch {
@@ -55,6 +59,9 @@ struct FtGemmTNTask {
   int M, N, R, taps;
   FtRowMap amap, bmap;
   int a_vec, b_vec, accumulate;
+  // strided batch (see FtGemmTask); dst += z0*sD0 + z1*sD1
+  int nz, nz1;
+  long sA0, sA1, sB0, sB1, sD0, sD1;
 };
 
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream);

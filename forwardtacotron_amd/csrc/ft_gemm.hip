@@ -83,7 +83,17 @@ __device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, boo
 // ld4_sel only.  The generic form predicates every element (odd sizes, unaligned views).
 template <int TM, int TN, bool BNC, bool FAST>
 __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
-  const FtGemmTask& T = batch.t[blockIdx.z];
+  const bool zbatch = batch.t[0].nz > 1;           // strided-batch launch: one task, blockIdx.z = instance
+  const FtGemmTask& T = batch.t[zbatch ? 0 : blockIdx.z];
+  const float* TA = T.A;
+  const float* TB = T.B;
+  float* TC = T.C;
+  if (zbatch) {
+    const int z0 = blockIdx.z / T.nz1, z1 = blockIdx.z - z0 * T.nz1;
+    TA += z0 * T.sA0 + z1 * T.sA1;
+    TB += z0 * T.sB0 + z1 * T.sB1;
+    TC += z0 * T.sC0 + z1 * T.sC1;
+  }
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDA = BM + 1;
   constexpr int LDB = BNC ? BN + 4 : BN + 1;
@@ -124,11 +134,11 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
     for (int p = 0; p < PA; ++p) {
       int ts = a_t[p] + shift;
       bool ok = a_ok[p] && ts >= 0 && ts < T.amap.Tvalid;
-      const float* ptr = T.A + (a_base[p] + (long)ts * T.amap.tstride) * T.lda + k;
-      if constexpr (FAST) ra[p] = ld4_sel(ptr, T.A, ok && k < T.K);
+      const float* ptr = TA + (a_base[p] + (long)ts * T.amap.tstride) * T.lda + k;
+      if constexpr (FAST) ra[p] = ld4_sel(ptr, TA, ok && k < T.K);
       else ra[p] = ld4(ptr, ok ? T.K - k : 0, T.a_vec);
     }
-    const float* Bj = T.B + (long)j * T.b_tap_stride;
+    const float* Bj = TB + (long)j * T.b_tap_stride;
     if constexpr (!BNC) {
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
           const int cb = row / T.cmap.Tlog;
           crow = (long)cb * T.cmap.bstride + (long)(row - cb * T.cmap.Tlog) * T.cmap.tstride;
         }
-        float* cp = T.C + crow * T.ldc + col;
+        float* cp = TC + crow * T.ldc + col;
         float v = acc[i][j][e] + bv;
         if (T.relu) v = fmaxf(v, 0.f);
         if (T.scale) v = v * sc + sh;
@@ -248,7 +258,16 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int tap = blockIdx.z / S, s = blockIdx.z - tap * S;
+  // blockIdx.z = ((instance * taps) + tap) * S + split
+  const int zts = blockIdx.z / S, s = blockIdx.z - zts * S;
+  const int zi = zts / T.taps, tap = zts - zi * T.taps;
+  const float* TA = T.A;
+  const float* TB = T.B;
+  if (T.nz > 1) {
+    const int z0 = zi / T.nz1, z1 = zi - z0 * T.nz1;
+    TA += z0 * T.sA0 + z1 * T.sA1;
+    TB += z0 * T.sB0 + z1 * T.sB1;
+  }
   const int r_begin = s * rows_per_split;
   const int r_end = min(T.R, r_begin + rows_per_split);
   const int tid = threadIdx.x;
@@ -266,8 +285,8 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       int ts = r - b * T.amap.Tlog + ashift;
       bool ok = r < r_end && ts >= 0 && ts < T.amap.Tvalid;
       int m = m0 + 4 * aq;
-      const float* ptr = T.A + ((long)b * T.amap.bstride + (long)ts * T.amap.tstride) * T.lda + m;
-      if constexpr (FAST) ra[p] = ld4_sel(ptr, T.A, ok && m < T.M);
+      const float* ptr = TA + ((long)b * T.amap.bstride + (long)ts * T.amap.tstride) * T.lda + m;
+      if constexpr (FAST) ra[p] = ld4_sel(ptr, TA, ok && m < T.M);
       else ra[p] = ld4(ptr, ok ? T.M - m : 0, T.a_vec);
     }
 #pragma unroll
@@ -277,8 +296,8 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       int ts = r - b * T.bmap.Tlog + bshift;
       bool ok = r < r_end && ts >= 0 && ts < T.bmap.Tvalid;
       int n = n0 + 4 * bq;
-      const float* ptr = T.B + ((long)b * T.bmap.bstride + (long)ts * T.bmap.tstride) * T.ldb + n;
-      if constexpr (FAST) rb[p] = ld4_sel(ptr, T.B, ok && n < T.N);
+      const float* ptr = TB + ((long)b * T.bmap.bstride + (long)ts * T.bmap.tstride) * T.ldb + n;
+      if constexpr (FAST) rb[p] = ld4_sel(ptr, TB, ok && n < T.N);
       else rb[p] = ld4(ptr, ok ? T.N - n : 0, T.b_vec);
     }
   };
@@ -334,19 +353,21 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
     }
 }
 
-// dst[m*ldm + n*ldn + tap*ldj] (+)= sum_s slab[tap*S+s][m][n]   (fixed order -> bitwise reproducible)
+// dst_z[m*ldm + n*ldn + tap*ldj] (+)= sum_s slab[(z*taps+tap)*S+s][m][n]   (fixed order -> reproducible)
 __global__ void ft_splitk_reduce_kernel(const float* slab, float* dst, int M, int N, int taps, int S,
-                                        long ldm, long ldn, long ldj, int accumulate) {
+                                        long ldm, long ldn, long ldj, int accumulate, int nz, int nz1, long sD0,
+                                        long sD1) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long total = (long)taps * M * N;
+  long total = (long)nz * taps * M * N;
   if (idx >= total) return;
-  int tap = (int)(idx / ((long)M * N));
-  long mn = idx - (long)tap * M * N;
+  int zt = (int)(idx / ((long)M * N));             // instance * taps + tap
+  long mn = idx - (long)zt * M * N;
+  int zi = zt / taps, tap = zt - zi * taps;
   int m = (int)(mn / N), n = (int)(mn - (long)m * N);
-  const float* p = slab + ((long)tap * S) * M * N + mn;
+  const float* p = slab + ((long)zt * S) * M * N + mn;
   float acc = 0.f;
   for (int s = 0; s < S; ++s) acc += p[(long)s * M * N];
-  float* d = dst + m * ldm + n * ldn + tap * ldj;
+  float* d = dst + (zi / nz1) * sD0 + (zi % nz1) * sD1 + m * ldm + n * ldn + tap * ldj;
   *d = accumulate ? *d + acc : acc;
 }
 
@@ -356,15 +377,16 @@ struct TNPlan {
 
 TNPlan plan_tn(const FtGemmTNTask& t) {
   TNPlan p;
-  bool small = ((long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128) * t.taps < 64) || t.M <= 64 || t.N <= 64;
+  const int nz = t.nz > 1 ? t.nz : 1;
+  bool small = ((long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128) * t.taps * nz < 64) || t.M <= 64 || t.N <= 64;
   p.tm = p.tn = small ? 1 : 2;
   int bm = 64 * p.tm;
-  long tiles = (long)ft_cdiv(t.M, bm) * ft_cdiv(t.N, bm) * t.taps;
+  long tiles = (long)ft_cdiv(t.M, bm) * ft_cdiv(t.N, bm) * t.taps * nz;
   long want = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
   long maxs = (t.R + 4 * BK - 1) / (4 * BK);      // at least 128 rows per split
   if (maxs < 1) maxs = 1;
   long S = want < maxs ? want : maxs;
-  if (S > 65535 / (t.taps > 0 ? t.taps : 1)) S = 65535 / t.taps;
+  if (S > 65535 / ((long)t.taps * nz)) S = 65535 / ((long)t.taps * nz);
   if (S < 1) S = 1;
   long rps = (t.R + S - 1) / S;
   rps = ((rps + BK - 1) / BK) * BK;
@@ -380,7 +402,7 @@ TNPlan plan_tn(const FtGemmTNTask& t) {
 
 size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& t) {
   TNPlan p = plan_tn(t);
-  return (size_t)p.S * t.taps * t.M * t.N;
+  return (size_t)p.S * t.taps * (t.nz > 1 ? t.nz : 1) * t.M * t.N;
 }
 
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream) {
@@ -392,17 +414,24 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
     FT_REQUIRE(t.M >= 0 && t.N >= 0 && t.K >= 0 && t.taps >= 1, "gemm_rows: bad dims");
     FT_REQUIRE(t.amap.Tlog > 0, "gemm_rows: bad row map");
     if (t.cmap.Tlog <= 0) t.cmap = ft_rowmap_identity(t.M);     // tasks built with memset(0): identity output
-    t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0);
-    t.b_vec = (t.ldb % 4 == 0) && (t.b_tap_stride % 4 == 0) && (((uintptr_t)t.B) % 16 == 0);
+    if (t.nz <= 1) {
+      t.nz = t.nz1 = 1;
+      t.sA0 = t.sA1 = t.sB0 = t.sB1 = t.sC0 = t.sC1 = 0;
+    }
+    FT_REQUIRE(t.nz == 1 || ntasks == 1, "gemm_rows: strided batch needs a single task");
+    FT_REQUIRE(t.nz1 >= 1 && t.nz % t.nz1 == 0, "gemm_rows: bad batch split");
+    t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0) && (t.sA0 % 4 == 0) && (t.sA1 % 4 == 0);
+    t.b_vec = (t.ldb % 4 == 0) && (t.b_tap_stride % 4 == 0) && (((uintptr_t)t.B) % 16 == 0) && (t.sB0 % 4 == 0) &&
+              (t.sB1 % 4 == 0);
     if (t.M > maxM) maxM = t.M;
     if (t.N > maxN) maxN = t.N;
-    tiles128 += (long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128);
+    tiles128 += (long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128) * t.nz;
   }
   if (maxM == 0 || maxN == 0) return FT_OK;
   for (int i = ntasks; i < FT_MAX_TASKS; ++i) batch->t[i] = batch->t[0];
   const bool big = tiles128 >= 192 && maxN > 64 && maxM > 64;
   const int bm = big ? 128 : 64;
-  dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), ntasks);
+  dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), ntasks == 1 ? batch->t[0].nz : ntasks);
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_rows: grid too large");
   bool fast = true;
   for (int i = 0; i < ntasks; ++i) {
@@ -432,14 +461,19 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   FtGemmTNTask t = task_in;
   FT_REQUIRE(t.M >= 0 && t.N >= 0 && t.R >= 0 && t.taps >= 1, "gemm_tn: bad dims");
   if (t.M == 0 || t.N == 0) return FT_OK;
-  t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0);
-  t.b_vec = (t.ldb % 4 == 0) && (((uintptr_t)t.B) % 16 == 0);
+  if (t.nz <= 1) {
+    t.nz = t.nz1 = 1;
+    t.sA0 = t.sA1 = t.sB0 = t.sB1 = t.sD0 = t.sD1 = 0;
+  }
+  FT_REQUIRE(t.nz1 >= 1 && t.nz % t.nz1 == 0, "gemm_tn: bad batch split");
+  t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0) && (t.sA0 % 4 == 0) && (t.sA1 % 4 == 0);
+  t.b_vec = (t.ldb % 4 == 0) && (((uintptr_t)t.B) % 16 == 0) && (t.sB0 % 4 == 0) && (t.sB1 % 4 == 0);
   TNPlan p = plan_tn(t);
-  size_t need = (size_t)p.S * t.taps * t.M * t.N;
+  size_t need = (size_t)p.S * t.taps * t.nz * t.M * t.N;
   FT_REQUIRE(workspace && workspace_floats >= need, "gemm_tn: workspace too small (%zu < %zu floats)",
              workspace_floats, need);
   const int bm = 64 * p.tm;
-  dim3 grid(ft_cdiv(t.M, bm), ft_cdiv(t.N, bm), p.S * t.taps);
+  dim3 grid(ft_cdiv(t.M, bm), ft_cdiv(t.N, bm), p.S * t.taps * t.nz);
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_tn: grid too large");
   const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
   if (p.tm == 2) {
@@ -451,8 +485,8 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   }
   int rc = ft_check_launch("gemm_tn");
   if (rc) return rc;
-  long total = (long)t.taps * t.M * t.N;
+  long total = (long)t.nz * t.taps * t.M * t.N;
   hipLaunchKernelGGL(ft_splitk_reduce_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, stream, workspace, t.dst,
-                     t.M, t.N, t.taps, p.S, t.ldm, t.ldn, t.ldj, t.accumulate);
+                     t.M, t.N, t.taps, p.S, t.ldm, t.ldn, t.ldj, t.accumulate, t.nz, t.nz1, t.sD0, t.sD1);
   return ft_check_launch("splitk_reduce");
 }

@@ -76,6 +76,43 @@ int ft_conv1d_bwd_weight(const float* dy, long lddy, const float* x, long ldx, f
                          int Cout, int k, int Tbuf, int Tvalid, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* ---- FastPitch building blocks (models/fast_pitch.py, common_layers.py:127-223) -------------------------- */
+/* nn.Conv1d WITH bias, odd k, padding k//2 (FFTBlock conv1 k=9 + ReLU, conv2 k=1; common_layers.py:161-164,178-180) */
+int ft_conv1d_bias_fwd(const float* x, long ldx, const float* wp, const float* bias, float* y, long ldy, int B, int T,
+                       int Cin, int Cout, int k, int relu, void* stream);
+/* strided-batch GEMMs for nn.MultiheadAttention (common_layers.py:158,172-174): nb0*nb1 independent instances,
+ * instance z -> (z0,z1) = (z/nb1, z%nb1), operand X_z = X + z0*sX0 + z1*sX1 (floats).
+ *   nt: C_z[M,N] = A_z[M,K] * B_z[N,K]^T   (scores = Q K^T ; dP = dCtx V^T)
+ *   nn: C_z[M,N] = A_z[M,K] * B_z[K,N]     (ctx = P V ; dQ = dS K)
+ *   tn: C_z[M,N] = A_z[R,M]^T * B_z[R,N]   (dV = P^T dCtx ; dK = dS^T Q), deterministic split + reduce */
+int ft_bgemm_nt(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
+                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, void* stream);
+int ft_bgemm_nn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
+                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, void* stream);
+size_t ft_bgemm_tn_workspace(int M, int N, int R, int nb0, int nb1);
+int ft_bgemm_tn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
+                long ldc, long sC0, long sC1, int M, int N, int R, int nb0, int nb1, void* workspace,
+                size_t workspace_bytes, void* stream);
+/* scores[B,nh,Tq,Tk] <- softmax(scale*scores + mask) in place; key_pad[B,Tk] bytes (non-zero = padded key) or NULL */
+int ft_softmax_fwd(float* scores, const unsigned char* key_pad, int B, int nh, int Tq, int Tk, float scale,
+                   void* stream);
+/* dprobs <- scale * P * (dprobs - rowsum(dprobs*P)) in place */
+int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, float scale, void* stream);
+/* nn.LayerNorm(D) over the last dim with an optional fused residual add: s = x (+res) (stored to sum_out if not
+ * NULL), y = LN(s); per-row mean / rstd saved.  bwd: dx (gradient wrt s) and dy_xhat = dy*xhat whose column
+ * sums are dgamma (dbeta = column sums of dy), via ft_colsum. */
+int ft_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* sum_out,
+                     float* y, float* mean, float* rstd, long rows, int D, float eps, void* stream);
+int ft_layernorm_bwd(const float* dy, const float* s, const float* gamma, const float* mean, const float* rstd,
+                     float* dx, float* dy_xhat, long rows, int D, void* stream);
+/* PositionalEncoding (common_layers.py:127-145): out = x + scale[0]*pe[t,:]; dscale = sum(dout*pe) */
+int ft_posenc_fwd(const float* x, const float* pe, const float* scale, float* out, int B, int T, int D,
+                  void* stream);
+size_t ft_posenc_workspace(void);
+int ft_posenc_bwd_scale(const float* dout, const float* pe, float* dscale, int B, int T, int D, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int ft_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream);
+
 /* ---- LengthRegulator (common_layers.py:12-24) ------------------------------------------------------- */
 /* scan: clamps dur[dur<0]=0 IN PLACE (as the reference does), r=(long)(dur+0.5); cum[b][0..Tx] exclusive
  * frame offsets (int32, [B,Tx+1]); total[b] = cum[b][Tx].  Caller reads max(total) to size the output. */

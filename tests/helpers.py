@@ -66,5 +66,49 @@ TINY_MULTI = dict(embed_dims=16, series_embed_dims=8, num_chars=135,
                   prenet_dropout=0.0, postnet_dims=12, postnet_k=3, prenet_num_highways=2,
                   postnet_dropout=0.0, n_mels=10, speaker_emb_dims=256, pitch_cond_emb_dims=4,
                   pitch_cond_categorical_dims=3)
+TINY_FP = dict(num_chars=135,
+               durpred_d_model=8, durpred_n_heads=2, durpred_layers=1, durpred_d_fft=12, durpred_dropout=0.0,
+               pitch_d_model=8, pitch_n_heads=1, pitch_layers=2, pitch_d_fft=12, pitch_dropout=0.0,
+               pitch_strength=1.0,
+               energy_d_model=8, energy_n_heads=2, energy_layers=1, energy_d_fft=8, energy_dropout=0.0,
+               energy_strength=0.5,
+               d_model=16, conv1_kernel=5, conv2_kernel=1,
+               prenet_layers=2, prenet_heads=2, prenet_fft=24, prenet_dropout=0.0,
+               postnet_layers=2, postnet_heads=4, postnet_fft=20, postnet_dropout=0.0, n_mels=10)
+
+FULL_FP = dict(num_chars=135,
+               durpred_d_model=128, durpred_n_heads=2, durpred_layers=4, durpred_d_fft=128, durpred_dropout=0.5,
+               pitch_d_model=128, pitch_n_heads=2, pitch_layers=4, pitch_d_fft=128, pitch_dropout=0.5,
+               pitch_strength=1.0,
+               energy_d_model=128, energy_n_heads=2, energy_layers=4, energy_d_fft=128, energy_dropout=0.5,
+               energy_strength=1.0,
+               d_model=256, conv1_kernel=9, conv2_kernel=1,
+               prenet_layers=4, prenet_heads=2, prenet_fft=1024, prenet_dropout=0.1,
+               postnet_layers=4, postnet_heads=2, postnet_fft=1024, postnet_dropout=0.1, n_mels=80)
+
+
+def sinusoid_pe(d_model, max_len=5000):
+    """The reference's deterministic `pe` buffer (common_layers.py:134-141), [max_len,1,d]."""
+    import math
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(1)
+
+
+def fp_state(d, prefix):
+    """FastPitch state_dict from a fixture: the truncated `pe` rows are checked against the formula and replaced
+    by the full-length buffer."""
+    sd = sub(d, prefix)
+    for k in list(sd):
+        if k.endswith('.pe'):
+            full = sinusoid_pe(sd[k].shape[-1])
+            assert maxdiff(full[:sd[k].shape[0]], sd[k]) == 0.0, k
+            sd[k] = full
+    return sd
+
+
 TRAIN_CFG_MULTI = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss_factor=0.1,
                        pitch_cond_loss_factor=0.1, clip_grad_norm=1.0)
