@@ -1,0 +1,59 @@
+// Shared pieces of the recurrence kernels (ft_rnn.hip: per-step launches + C entry points;
+// ft_rnn_persist.hip: one-launch persistent forms).
+#pragma once
+#include "ft_common.h"
+
+constexpr int RLD = 20;     // LDS row stride of the 16x16 partial tiles
+constexpr int GCH = 8;      // K groups (16 k each) a wave keeps in registers
+
+struct RnnFwdArgs {
+  const float* xp;        // [T,B,ND*G*H]   x W_ih^T + b_ih   (time-major)
+  const float* whh[2];    // [G*H,H]
+  const float* bhh[2];    // [G*H]
+  float* out;             // [T,B,ND*H]  raw hidden states (zero where inactive)
+  float* cst;             // LSTM: [T,B,ND*H] cell states
+  float* gates;           // optional [T,B,ND,4*H] saved activations (training)
+  const long* lens;       // optional [B]
+  int B, T, H, ND, s, vec;
+};
+
+struct RnnBwdArgs {
+  const float* dout;      // [T,B,ND*H]
+  const float* out;       // [T,B,ND*H] raw hidden states
+  const float* cst;       // LSTM cell states
+  const float* gates;     // [T,B,ND,4H]
+  const float* whhT[2];   // [H, G*H]  (W_hh transposed)
+  float* dxp;             // [T,B,ND*G*H]  d(pre-activation) wrt the input projection
+  float* dhp;             // GRU only: [T,B,ND*G*H] d wrt the hidden projection (n gate scaled by r); LSTM: == dxp
+  float* carry;           // [B,ND,H]  GRU: dh*z ; LSTM: dc*f  (per-step kernels only)
+  const long* lens;
+  int B, T, H, ND, s, vec;
+};
+
+__device__ __forceinline__ void mfma4(const float4& a, const float4& b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+}
+
+// partial tile store: lane holds column lane&15, rows (lane>>4)*4 + e
+template <int MT>
+__device__ __forceinline__ void store_partials(float* red, int wave, int lane, const f32x4 (&acc)[MT]) {
+  float* r = red + wave * (MT * 16 * RLD);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[(m * 16 + (lane >> 4) * 4 + e) * RLD + (lane & 15)] = acc[m][e];
+}
+
+__device__ __forceinline__ int clamp_len(const long* lens, int b, int T) {
+  if (!lens) return T;
+  long l = lens[b];
+  return l < 0 ? 0 : (l > T ? T : (int)l);
+}
+
+// One-launch persistent recurrences (ft_rnn_persist.hip).  Return FT_OK if launched, -1 if the persistent form does
+// not apply (the caller then issues the per-step kernels).
+int ft_rnn_fwd_persistent(int G, RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream);
+int ft_rnn_bwd_persistent(int G, RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -1,0 +1,577 @@
+// PERSISTENT bidirectional GRU / LSTM recurrences for gfx950: one launch runs all T steps.
+//
+// Why: the XCD L2s do not keep W_hh across kernel boundaries, so per-step launches re-stream the recurrent weights
+// from Infinity Cache every step (measured 14.8 MB/step, profiles/r01_pmc_rnn_step.txt).  Here every wave keeps its
+// W_hh fragments in REGISTERS for the whole sequence and only h (forward) or d(gates) (backward) travels between
+// workgroups, through a small exchange buffer:
+//   exchange layout  xb[parity][group = (dir, batch group of 16)][k/4][16][4]   (k = contraction index; a storing wave
+//                    owns whole [16][4] blocks = two full 128-B lines, written by ONE store instruction)
+//   producer: write-through (sc1) stores FIRST -> that wave's s_waitcnt vmcnt(0) -> its lane 0 adds 1 to the
+//             arrival-counter shard of the block (agent scope).  The step's other outputs (h / c / saved gates,
+//             d(pre-activations)) are plain stores issued AFTER the signal, off the critical path.
+//   consumer: 16 lanes of wave 0 poll the 16 shards of the group with sc1 loads until each holds
+//             step * (#producing waves of the shard); workgroup barrier; sc1 16-B loads of the operand rows.
+//   (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", row "each storing wave for itself".)
+// Step s reads parity (s-1)&1 and writes parity s&1; a workgroup can only be one step ahead of the slowest producer it
+// depends on, so two parities suffice.  Every spin is bounded: on timeout the workgroup raises *err and leaves; all
+// others then time out at the same step, so the grid always drains.  All workgroups must be co-resident: the host
+// checks the grid against the occupancy query, otherwise (or with FT_RNN_PERSISTENT=0) the per-step kernels run.
+//
+// What the per-step time is made of (s_memtime phase profile, LSTM 512, B=32: poll 1.0 us, operand loads 0.8,
+// MFMA 0.6, LDS reduce + barrier 0.6, cell 0.6, store drain 0.4, top 0.4) shaped this version:
+//   * a workgroup covers 16 batch rows (not 32): the operand volume per CU per step (rows x K x 4 B, streamed
+//     through one 64 B/clk L1 path) halves, and a (dir, 16-row) group has half as many producers to wait for;
+//   * the x-projection / saved-activation operands of step s+1 are requested during step s (loads return in order, so
+//     a same-step request would sit in front of the exchange loads with its HBM latency);
+//   * 1-D grid with an XCD-aware decode: the 8 XCDs take contiguous ranges of (group, chunk), so a group's exchange
+//     lines and the 128-B lines of out / gates / xp rows are shared inside one or two L2s instead of all eight.
+#include <stdlib.h>
+
+#include "ft_rnn.h"
+
+namespace {
+
+constexpr int NSH = 16;                // arrival-counter shards per group
+constexpr int CSTRIDE = 32;            // one counter per 128-B line
+constexpr unsigned MAX_SPINS = 1u << 18;
+constexpr int MB = 16;                 // batch rows per workgroup
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Geom {
+  int nchunks, nbg, total;             // chunks per group, batch groups, workgroups that have work
+  int xcd_aware, sig_per_wave;
+};
+
+__device__ __forceinline__ float4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);     // aux 16 = sc1
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// wave 0 waits until every shard k holds >= step * n_k arrivals; returns false on timeout (wave-uniform)
+__device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned step, int nprod, int lane) {
+  bool ok = true;
+  if (lane < NSH) {
+    const unsigned nk = lane < nprod ? (unsigned)((nprod - lane + NSH - 1) / NSH) : 0u;
+    const unsigned target = step * nk;
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt + lane * CSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > MAX_SPINS) {
+        ok = false;
+        break;
+      }
+    }
+  }
+  return __all(ok);
+}
+
+// XCD-aware decode of the 1-D grid: dispatch is round-robin over the 8 XCDs, so XCD x runs work items
+// [x*per, (x+1)*per).  Only locality depends on that; any placement is correct.
+__device__ __forceinline__ bool decode(const Geom& g, int& d, int& bgp, int& chunk, int& grp) {
+  const int lin = blockIdx.x, per = gridDim.x >> 3;
+  const int w = g.xcd_aware ? (lin & 7) * per + (lin >> 3) : lin;
+  if (w >= g.total) return false;
+  grp = w / g.nchunks;
+  chunk = w - grp * g.nchunks;
+  d = grp / g.nbg;
+  bgp = grp - d * g.nbg;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward: workgroup = 16 batch rows x 8 hidden units (all G gates = 2 column tiles), K = H over NW waves
+// ---------------------------------------------------------------------------------------------------
+template <int G, int NW>
+__global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
+                                                                     unsigned* err, unsigned xb_bytes) {
+  constexpr int UB = 8, NT = 2;
+  __shared__ float red[NW * NT * 16 * RLD];
+  __shared__ int s_ok;
+  int d, bgp, chunk, grp;
+  if (!decode(geo, d, bgp, chunk, grp)) return;
+  const int u0 = chunk * UB, b0 = bgp * MB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int H = a.H, T = a.T, nq = H / 4;
+  const long ldo = (long)a.ND * H;
+  const long ldx = (long)a.ND * G * H;
+  const long grp_floats = (long)nq * MB * 4;
+  const long par_floats = (long)2 * geo.nbg * grp_floats;                 // one parity
+  const long base_floats = (long)grp * grp_floats;
+  unsigned* mycnt = cnt + (long)grp * NSH * CSTRIDE;
+  const int nprod = (geo.sig_per_wave ? 2 : 1) * geo.nchunks;             // signalling waves per group
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xb_bytes, 0x00020000);
+
+  // ---- resident W_hh fragments of this wave: tile nt, column l15 -> (gate, unit) = ((nt*16+l15)/8, (nt*16+l15)%8)
+  const int ngroups = H / 16;
+  const int gpw = (ngroups + NW - 1) / NW;
+  const int g0 = wave * gpw, g1 = min(ngroups, g0 + gpw);
+  float4 bv[NT][GCH];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = nt * 16 + l15, gj = col / UB, ul = col - gj * UB;
+    const bool valid = gj < G;
+    const float* brow = a.whh[d] + (valid ? ((long)gj * H + u0 + ul) * H : 0);
+#pragma unroll
+    for (int c = 0; c < GCH; ++c)
+      bv[nt][c] = (valid && g0 + c < g1) ? *reinterpret_cast<const float4*>(brow + 16 * (g0 + c) + 4 * q)
+                                         : make_float4(0, 0, 0, 0);
+  }
+
+  // ---- cell threads (waves 0 and 1): wave jq owns units 4*jq..4*jq+3 of the chunk = one [16][4] exchange block
+  const int jq = tid >> 6, ci = (tid >> 2) & 15, jj = tid & 3;
+  const int cu = 4 * jq + jj;
+  const int cb = b0 + ci, cun = u0 + cu;
+  const bool sthr = tid < 128;
+  const bool cthr = sthr && cb < a.B;
+  const int L = cthr ? clamp_len(a.lens, cb, T) : 0;
+  float bg[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bg[g] = sthr ? a.bhh[d][g * H + cun] : 0.f;
+  float hprev = 0.f, cprev = 0.f;
+  float xg[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) xg[g] = 0.f;
+  if (cthr && 0 < L) {
+    const int ct = d == 0 ? 0 : L - 1;
+    const float* xr = a.xp + ((long)ct * a.B + cb) * ldx + (long)d * G * H + cun;
+#pragma unroll
+    for (int g = 0; g < G; ++g) xg[g] = xr[(long)g * H];
+  }
+
+  for (int s = 0; s < T; ++s) {
+    const bool cact = cthr && s < L;
+    const int ct = d == 0 ? s : L - 1 - s;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[nt][e] = 0.f;
+    float4 av[GCH];
+    if (s > 0) {
+      if (wave == 0) {
+        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
+        if (lane == 0) s_ok = ok;
+      }
+      __syncthreads();
+      if (!s_ok) {
+        if (tid == 0) atomicExch(err, 1u);
+        return;
+      }
+      const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
+#pragma unroll
+      for (int c = 0; c < GCH; ++c)
+        if (g0 + c < g1) {
+          const long quad = 4 * (g0 + c) + q;
+          av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+        }
+    }
+    // next step's x projection, requested behind the exchange loads
+    float xn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) xn[g] = 0.f;
+    if (cthr && s + 1 < L) {
+      const int cn = d == 0 ? s + 1 : L - 2 - s;
+      const float* xr = a.xp + ((long)cn * a.B + cb) * ldx + (long)d * G * H + cun;
+#pragma unroll
+      for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
+    }
+    if (s > 0) {
+#pragma unroll
+      for (int c = 0; c < GCH; ++c)
+        if (g0 + c < g1) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) mfma4(av[c], bv[nt][c], acc[nt]);
+        }
+    }
+    store_partials<NT>(red, wave, lane, acc);
+    __syncthreads();
+
+    float hnew = 0.f, cnew = 0.f, sg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cact) {
+      float hp[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int col = g * UB + cu;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w * (NT * 16 * RLD) + ((col >> 4) * 16 + ci) * RLD + (col & 15)];
+        hp[g] = v + bg[g];
+      }
+      if (G == 3) {
+        const float r = ft_sigmoid(xg[0] + hp[0]);
+        const float z = ft_sigmoid(xg[1] + hp[1]);
+        const float n = ft_tanh(xg[2] + r * hp[2]);
+        hnew = (1.f - z) * n + z * hprev;
+        sg[0] = r; sg[1] = z; sg[2] = n; sg[3] = hp[2];
+      } else {
+        const float ig = ft_sigmoid(xg[0] + hp[0]);
+        const float fg = ft_sigmoid(xg[1] + hp[1]);
+        const float gg = ft_tanh(xg[2] + hp[2]);
+        const float og = ft_sigmoid(xg[G - 1] + hp[G - 1]);
+        cnew = fg * cprev + ig * gg;
+        cprev = cnew;
+        hnew = og * ft_tanh(cnew);
+        sg[0] = ig; sg[1] = fg; sg[2] = gg; sg[3] = og;
+      }
+      hprev = hnew;
+      // exchange block [2*chunk + jq][16][4] of parity s&1 (write-through), before anything else
+      float* xw = xb + (long)(s & 1) * par_floats + base_floats + (((long)2 * chunk + jq) * MB + ci) * 4 + jj;
+      __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (geo.sig_per_wave) {
+      if (sthr) {                                          // waves 0 and 1, wave-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_fetch_add(mycnt + ((2 * chunk + jq) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_fetch_add(mycnt + (chunk % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (cact) {                                          // the step's outputs proper: off the recurrence's path
+      const long o = ((long)ct * a.B + cb) * ldo + (long)d * H + cun;
+      a.out[o] = hnew;
+      if (G == 4) a.cst[o] = cnew;
+      if (a.gates) {
+        float* gs = a.gates + (((long)ct * a.B + cb) * a.ND + d) * 4 * H + cun;
+        gs[0] = sg[0]; gs[H] = sg[1]; gs[2 * H] = sg[2]; gs[3 * H] = sg[3];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) xg[g] = xn[g];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward: workgroup = 16 batch rows x 16 hidden units, K = G*H over NW waves
+// ---------------------------------------------------------------------------------------------------
+template <int G, int NW, int GW>
+__global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs a, Geom geo, float* xb, unsigned* cnt,
+                                                                     unsigned* err, unsigned xb_bytes) {
+  __shared__ float red[NW * 16 * RLD];
+  __shared__ int s_ok;
+  int d, bgp, chunk, grp;
+  if (!decode(geo, d, bgp, chunk, grp)) return;
+  const int u0 = chunk * 16, b0 = bgp * MB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int H = a.H, T = a.T, K = G * H, nq = K / 4;
+  const long ldg = (long)a.ND * K;
+  const long ldo = (long)a.ND * H;
+  const long grp_floats = (long)nq * MB * 4;
+  const long par_floats = (long)2 * geo.nbg * grp_floats;
+  const long base_floats = (long)grp * grp_floats;
+  unsigned* mycnt = cnt + (long)grp * NSH * CSTRIDE;
+  const int nprod = (geo.sig_per_wave ? 4 : 1) * geo.nchunks;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xb_bytes, 0x00020000);
+
+  // ---- resident W_hh^T fragments: column l15 = unit u0+l15 ; K groups [g0,g1)
+  const float* brow = a.whhT[d] + (long)(u0 + l15) * K;
+  const int ngroups = K / 16;
+  const int gpw = (ngroups + NW - 1) / NW;
+  const int g0 = wave * gpw, g1 = min(ngroups, g0 + gpw);
+  float4 bv[GW];
+#pragma unroll
+  for (int c = 0; c < GW; ++c)
+    bv[c] = (g0 + c < g1) ? *reinterpret_cast<const float4*>(brow + 16 * (g0 + c) + 4 * q) : make_float4(0, 0, 0, 0);
+
+  // ---- cell threads (first 256): wave j4 owns units 4*j4..4*j4+3 -> whole [16][4] exchange blocks, one per gate
+  const int j4 = tid >> 6, ci = (tid >> 2) & 15, jj = tid & 3;
+  const int cj = 4 * j4 + jj;
+  const int cb = b0 + ci, cun = u0 + cj;
+  const bool sthr = tid < 256;
+  const bool cthr = sthr && cb < a.B;
+  const int L = cthr ? clamp_len(a.lens, cb, T) : 0;
+  float carry = 0.f;
+
+  // saved activations / upstream gradient of one step (requested a step ahead)
+  float gv[4] = {0.f, 0.f, 0.f, 0.f}, dov = 0.f, cc = 0.f, prev = 0.f;
+  auto request = [&](int sn, float (&rgv)[4], float& rdo, float& rcc, float& rprev) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rgv[g] = 0.f;
+    rdo = 0.f; rcc = 0.f; rprev = 0.f;
+    if (cthr && sn < L) {
+      const int ct = d == 0 ? L - 1 - sn : sn;
+      const int tprev = d == 0 ? ct - 1 : ct + 1;
+      const bool has_prev = tprev >= 0 && tprev < L;
+      const long o = ((long)ct * a.B + cb) * ldo + (long)d * H + cun;
+      const long op = ((long)tprev * a.B + cb) * ldo + (long)d * H + cun;
+      const float* gs = a.gates + (((long)ct * a.B + cb) * a.ND + d) * 4 * H + cun;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rgv[g] = gs[(long)g * H];
+      rdo = a.dout[o];
+      if (G == 3) {
+        rprev = has_prev ? a.out[op] : 0.f;
+      } else {
+        rcc = a.cst[o];
+        rprev = has_prev ? a.cst[op] : 0.f;
+      }
+    }
+  };
+  request(0, gv, dov, cc, prev);
+
+  for (int s = 0; s < T; ++s) {
+    const bool cact = cthr && s < L;
+    const int ct = d == 0 ? L - 1 - s : s;
+    f32x4 acc[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][e] = 0.f;
+    float4 av[GW];
+    if (s > 0) {
+      if (wave == 0) {
+        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
+        if (lane == 0) s_ok = ok;
+      }
+      __syncthreads();
+      if (!s_ok) {
+        if (tid == 0) atomicExch(err, 1u);
+        return;
+      }
+      const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
+#pragma unroll
+      for (int c = 0; c < GW; ++c)
+        if (g0 + c < g1) {
+          const long quad = 4 * (g0 + c) + q;
+          av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+        }
+    }
+    float ngv[4], ndo, ncc, nprev;
+    request(s + 1, ngv, ndo, ncc, nprev);
+    if (s > 0) {
+#pragma unroll
+      for (int c = 0; c < GW; ++c)
+        if (g0 + c < g1) mfma4(av[c], bv[c], acc[0]);
+    }
+    store_partials<1>(red, wave, lane, acc);
+    __syncthreads();
+
+    float dgx[4] = {0.f, 0.f, 0.f, 0.f}, dgh2 = 0.f;
+    if (cact) {
+      float rec = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) rec += red[w * (16 * RLD) + ci * RLD + cj];
+      if (G == 3) {
+        const float dh = dov + rec + carry;
+        const float r = gv[0], z = gv[1], n = gv[2], hn = gv[3];
+        const float dz = dh * (prev - n) * z * (1.f - z);
+        const float dn = dh * (1.f - z) * (1.f - n * n);
+        const float dr = dn * hn * r * (1.f - r);
+        dgx[0] = dr; dgx[1] = dz; dgx[2] = dn;
+        dgh2 = dn * r;
+        carry = dh * z;
+      } else {
+        const float dh = dov + rec;
+        const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+        const float tc = ft_tanh(cc);
+        const float dc = dh * og * (1.f - tc * tc) + carry;
+        dgx[0] = dc * gg * ig * (1.f - ig);
+        dgx[1] = dc * prev * fg * (1.f - fg);
+        dgx[2] = dc * ig * (1.f - gg * gg);
+        dgx[G - 1] = dh * tc * og * (1.f - og);
+        dgh2 = dgx[2];
+        carry = dc * fg;
+      }
+    }
+    if (cthr) {
+      // exchange: k = g*H + cun -> block k/4 = (g*H + u0)/4 + j4, row ci, slot jj ; a finished item's rows are
+      // published as zeros for the workgroups that still multiply them
+      float* xw = xb + (long)(s & 1) * par_floats + base_floats;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float v = (G == 3 && g == 2) ? dgh2 : dgx[g];
+        __hip_atomic_store(xw + (((long)(g * H + u0) / 4 + j4) * MB + ci) * 4 + jj, v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (geo.sig_per_wave) {
+      if (sthr) {                                          // waves 0..3, wave-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_fetch_add(mycnt + ((4 * chunk + j4) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_fetch_add(mycnt + (chunk % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (cact) {
+      float* dx = a.dxp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
+#pragma unroll
+      for (int g = 0; g < G; ++g) dx[(long)g * H] = dgx[g];
+      if (G == 3) {
+        float* dhh = a.dhp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
+        dhh[0] = dgx[0]; dhh[H] = dgx[1]; dhh[2 * H] = dgh2;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gv[g] = ngv[g];
+    dov = ndo; cc = ncc; prev = nprev;
+  }
+}
+
+int g_persistent = -1;      // -1: take FT_RNN_PERSISTENT from the environment
+bool persistent_enabled() {
+  if (g_persistent < 0) {
+    const char* e = getenv("FT_RNN_PERSISTENT");
+    g_persistent = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_persistent == 1;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+    if (cus <= 0) cus = 1;
+  }
+  return cus;
+}
+
+struct PersistWs {
+  float* xb;
+  unsigned* cnt;
+  unsigned* err;
+  size_t xb_bytes, total_bytes;
+};
+// workspace = [err + counters | exchange buffer]; both zeroed per call
+PersistWs carve_ws(void* ws, int ngrp, int K) {
+  PersistWs p;
+  size_t cnt_bytes = (size_t)(1 + ngrp * NSH) * CSTRIDE * sizeof(unsigned);
+  p.err = (unsigned*)ws;
+  p.cnt = p.err + CSTRIDE;
+  p.xb_bytes = (size_t)2 * ngrp * (K / 4) * MB * 4 * sizeof(float);
+  p.xb = (float*)((char*)ws + cnt_bytes);
+  p.total_bytes = cnt_bytes + p.xb_bytes;
+  return p;
+}
+
+template <typename KernelT>
+bool grid_fits(KernelT kernel, int block, long nblocks) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess) return false;
+  if (per_cu > 2) per_cu = 2;      // stay well inside what the dispatcher really admits
+  return per_cu >= 1 && nblocks <= (long)per_cu * device_cus();
+}
+
+template <int G, int NW>
+int launch_fwd_persist(const RnnFwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
+  if (!grid_fits(ft_rnn_fwd_persist_kernel<G, NW>, NW * 64, grid)) return -1;
+  (void)hipMemsetAsync(p.err, 0, p.total_bytes, stream);
+  hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
+                     p.err, (unsigned)p.xb_bytes);
+  return ft_check_launch("rnn_fwd_persistent");
+}
+
+template <int G>
+int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!persistent_enabled() || !ws || a.T < 2) return -1;
+  const int H = a.H, B = a.B;
+  if (!a.vec || H % 16 != 0) return -1;
+  const int ngroups = H / 16;
+  const int NW = ngroups > 16 ? 8 : 4;
+  if (ft_cdiv(ngroups, NW) > GCH) return -1;
+  Geom geo;
+  geo.nchunks = H / 8;
+  geo.nbg = ft_cdiv(B, MB);
+  geo.total = 2 * geo.nbg * geo.nchunks;
+  geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
+  geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
+  PersistWs p = carve_ws(ws, 2 * geo.nbg, H);
+  if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
+  const int grid = 8 * ft_cdiv(geo.total, 8);
+  a.s = 0;
+  return NW == 8 ? launch_fwd_persist<G, 8>(a, geo, p, grid, stream) : launch_fwd_persist<G, 4>(a, geo, p, grid, stream);
+}
+
+template <int G, int NW, int GW>
+int launch_bwd_persist(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
+  if (!grid_fits(ft_rnn_bwd_persist_kernel<G, NW, GW>, NW * 64, grid)) return -1;
+  (void)hipMemsetAsync(p.err, 0, p.total_bytes, stream);
+  hipLaunchKernelGGL((ft_rnn_bwd_persist_kernel<G, NW, GW>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
+                     p.err, (unsigned)p.xb_bytes);
+  return ft_check_launch("rnn_bwd_persistent");
+}
+
+template <int G>
+int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (!persistent_enabled() || !ws || a.T < 2) return -1;
+  const int H = a.H, B = a.B, K = G * H;
+  if (!a.vec || H % 16 != 0) return -1;
+  const int ngroups = K / 16;
+  // waves x resident K groups per wave: 8 waves keep up to 16 groups each (256 registers per lane at 2 waves per
+  // SIMD); 16 waves would cap a lane at 128 registers and spill the LSTM-512 working set
+  const int NW = ngroups > 128 ? 16 : (ngroups > 16 ? 8 : 4);
+  const int GW = ngroups > 64 ? 16 : 8;
+  if (ft_cdiv(ngroups, NW) > GW) return -1;
+  Geom geo;
+  geo.nchunks = H / 16;
+  geo.nbg = ft_cdiv(B, MB);
+  geo.total = 2 * geo.nbg * geo.nchunks;
+  geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
+  geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
+  PersistWs p = carve_ws(ws, 2 * geo.nbg, K);
+  if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
+  const int grid = 8 * ft_cdiv(geo.total, 8);
+  a.s = 0;
+  if (NW == 16) return launch_bwd_persist<G, 16, 16>(a, geo, p, grid, stream);
+  if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16>(a, geo, p, grid, stream)
+                               : launch_bwd_persist<G, 8, 8>(a, geo, p, grid, stream);
+  return launch_bwd_persist<G, 4, 8>(a, geo, p, grid, stream);
+}
+
+}  // namespace
+
+int ft_rnn_fwd_persistent(int G, RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return G == 3 ? fwd_persistent<3>(a, ws, ws_bytes, stream) : fwd_persistent<4>(a, ws, ws_bytes, stream);
+}
+int ft_rnn_bwd_persistent(int G, RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {
+  return G == 3 ? bwd_persistent<3>(a, ws, ws_bytes, stream) : bwd_persistent<4>(a, ws, ws_bytes, stream);
+}
+
+extern "C" {
+
+size_t ft_rnn_workspace(int gates, int B, int H) {
+  if (gates < 3 || gates > 4 || B <= 0 || H <= 0 || H % 16 != 0) return 0;
+  const int ngrp = 2 * ft_cdiv(B, MB);
+  PersistWs f = carve_ws(nullptr, ngrp, H);
+  PersistWs b = carve_ws(nullptr, ngrp, gates * H);
+  return f.total_bytes > b.total_bytes ? f.total_bytes : b.total_bytes;
+}
+
+int ft_rnn_set_persistent(int enabled) {
+  int old = persistent_enabled() ? 1 : 0;
+  g_persistent = enabled ? 1 : 0;
+  return old;
+}
+
+int ft_rnn_status(const void* workspace, void* stream) {
+  if (!workspace) return 0;
+  unsigned flag = 0;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+      hipMemcpy(&flag, workspace, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess) {
+    ft_set_error("rnn_status: HIP error while reading the status word");
+    return FT_ERR_HIP;
+  }
+  if (flag != 0) {
+    ft_set_error("persistent recurrence timed out waiting for another workgroup (grid not co-resident?); "
+                 "set FT_RNN_PERSISTENT=0 to use the per-step kernels");
+    return FT_ERR_HIP;
+  }
+  return FT_OK;
+}
+
+}  // extern "C"
