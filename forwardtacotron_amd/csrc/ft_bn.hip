@@ -78,18 +78,91 @@ __global__ __launch_bounds__(256) void ft_col_partial_kernel(const float* __rest
   }
 }
 
-__global__ void ft_bn_finalize_kernel(const double* __restrict__ partial, int nchunks, int B, int Tbuf, int C, int group,
-                                      float momentum, float eps, float* __restrict__ running_mean,
-                                      float* __restrict__ running_var, long* __restrict__ nbt,
-                                      float* __restrict__ save_mean, float* __restrict__ save_rstd) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < nchunks; ++i) {
-    s0 += partial[((long)i * C + c) * 2 + 0];
-    s1 += partial[((long)i * C + c) * 2 + 1];
+// mode 2 with 16-B lanes (C % 4 == 0, 16-B aligned rows): 16 row lanes x 16 column quads per block, four rows in
+// flight per lane; the 16 row-lane sums are combined in fixed order
+__global__ __launch_bounds__(256) void ft_colsum4_partial_kernel(const float* __restrict__ x, long ldx, long rows, int C,
+                                                                 int rows_per_chunk, double* __restrict__ partial) {
+  __shared__ double red[16][65];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cq * 4;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C) {
+    for (long r = r0 + rl; r < r1; r += 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long rr = r + 16 * u;
+        v[u] = rr < r1 ? *reinterpret_cast<const float4*>(x + rr * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[0] += (double)v[u].x;
+        s[1] += (double)v[u].y;
+        s[2] += (double)v[u].z;
+        s[3] += (double)v[u].w;
+      }
+    }
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cq * 4 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < C) {
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += red[i][threadIdx.x];
+      partial[((long)blockIdx.y * C + cc) * 2 + 0] = a;
+      partial[((long)blockIdx.y * C + cc) * 2 + 1] = 0.0;
+    }
+  }
+}
+
+// ordered two-level sum of the chunk partials of column c: 8 lanes take contiguous chunk ranges, lane 0 of the group
+// adds the 8 range sums in range order (deterministic; 8x shorter dependent chain than one serial loop)
+constexpr int FIN_PARTS = 8;
+__device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int nchunks, int C, int c, int part,
+                                             double (*sh)[FIN_PARTS][2], int slot, double& s0, double& s1) {
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    const int per = (nchunks + FIN_PARTS - 1) / FIN_PARTS;
+    const int i0 = part * per, i1 = min(nchunks, i0 + per);
+    for (int i = i0; i < i1; ++i) {
+      a0 += partial[((long)i * C + c) * 2 + 0];
+      a1 += partial[((long)i * C + c) * 2 + 1];
+    }
+  }
+  sh[slot][part][0] = a0;
+  sh[slot][part][1] = a1;
+  __syncthreads();
+  s0 = 0.0;
+  s1 = 0.0;
+  if (part == 0) {
+#pragma unroll
+    for (int p = 0; p < FIN_PARTS; ++p) {
+      s0 += sh[slot][p][0];
+      s1 += sh[slot][p][1];
+    }
+  }
+}
+
+// block = 32 columns x 8 parts
+__global__ __launch_bounds__(256) void ft_bn_finalize_kernel(const double* __restrict__ partial, int nchunks, int B,
+                                                             int Tbuf, int C, int group, float momentum, float eps,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, long* __restrict__ nbt,
+                                                             float* __restrict__ save_mean,
+                                                             float* __restrict__ save_rstd) {
+  __shared__ double sh[32][FIN_PARTS][2];
+  const int slot = threadIdx.x >> 3, part = threadIdx.x & 7;
+  const int c = blockIdx.x * 32 + slot;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  double s0, s1;
+  sum_partials(partial, nchunks, C, c, part, sh, slot, s0, s1);
+  if (part != 0 || c >= C) return;
   double n = (double)B * (double)tvalid_of(c, Tbuf, group);
   double mu = s0 / n;
   double var = s1 / n - mu * mu;
@@ -104,15 +177,15 @@ __global__ void ft_bn_finalize_kernel(const double* __restrict__ partial, int nc
 }
 
 // finalize of modes 1 / 2: out0[c] = sum0, out1[c] = sum1 (floats)
-__global__ void ft_col_finalize_kernel(const double* __restrict__ partial, int nchunks, int C, float* __restrict__ out0,
-                                       float* __restrict__ out1, float scale0, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < nchunks; ++i) {
-    s0 += partial[((long)i * C + c) * 2 + 0];
-    s1 += partial[((long)i * C + c) * 2 + 1];
-  }
+__global__ __launch_bounds__(256) void ft_col_finalize_kernel(const double* __restrict__ partial, int nchunks, int C,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              float scale0, int accumulate) {
+  __shared__ double sh[32][FIN_PARTS][2];
+  const int slot = threadIdx.x >> 3, part = threadIdx.x & 7;
+  const int c = blockIdx.x * 32 + slot;
+  double s0, s1;
+  sum_partials(partial, nchunks, C, c, part, sh, slot, s0, s1);
+  if (part != 0 || c >= C) return;
   if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)(s0 * scale0);
   if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)s1;
 }
@@ -214,7 +287,7 @@ int ft_bn_train_fwd(const float* y, const float* gamma, const float* beta, const
   ChunkPlan p = plan_chunks((long)B * Tbuf, C);
   hipLaunchKernelGGL(ft_col_partial_kernel<0>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, nullptr,
                      nullptr, nullptr, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
-  hipLaunchKernelGGL(ft_bn_finalize_kernel, dim3(ft_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace,
+  hipLaunchKernelGGL(ft_bn_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, B, Tbuf, C, group, momentum, eps, running_mean, running_var, num_batches_tracked,
                      save_mean, save_rstd);
   if (out && Tout > 0) {
@@ -234,7 +307,7 @@ int ft_bn_bwd(const float* dout, const float* y, const float* gamma, const float
   ChunkPlan p = plan_chunks((long)B * Tbuf, C);
   hipLaunchKernelGGL(ft_col_partial_kernel<1>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, dout,
                      save_mean, save_rstd, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
-  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace,
+  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, C, dbeta, dgamma, 1.0f, 0);
   long total = (long)B * Tbuf * C;
   hipLaunchKernelGGL(ft_bn_bwd_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, dout, y, save_mean, save_rstd,
@@ -263,9 +336,13 @@ int ft_colsum(const float* x, long ldx, float* out, int rows, int C, float scale
   }
   FT_REQUIRE(workspace && workspace_bytes >= ft_colsum_workspace(rows, C), "colsum: workspace too small");
   ChunkPlan p = plan_chunks(rows, C);
-  hipLaunchKernelGGL(ft_col_partial_kernel<2>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, x, ldx, nullptr,
-                     nullptr, nullptr, 1, rows, rows, C, 0, p.rows_per_chunk, (double*)workspace);
-  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 128)), dim3(128), 0, s, (const double*)workspace,
+  if (C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0)
+    hipLaunchKernelGGL(ft_colsum4_partial_kernel, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, x, ldx, (long)rows, C,
+                       p.rows_per_chunk, (double*)workspace);
+  else
+    hipLaunchKernelGGL(ft_col_partial_kernel<2>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, x, ldx, nullptr,
+                       nullptr, nullptr, 1, rows, rows, C, 0, p.rows_per_chunk, (double*)workspace);
+  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, C, out, nullptr, scale, accumulate);
   return ft_check_launch("colsum");
 }

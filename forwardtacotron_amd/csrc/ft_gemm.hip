@@ -398,6 +398,39 @@ TNPlan plan_tn(const FtGemmTNTask& t) {
   return p;
 }
 
+// FT_GEMM_LOG=1: every launch is timed with HIP events on its stream (synchronising) and one line per launch goes
+// to stderr -- a profiling aid for tools/gemm_report.py, never enabled in a timed run.
+struct GemmLog {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t stream = nullptr;
+  static bool on() {
+    static int v = -1;
+    if (v < 0) {
+      const char* e = getenv("FT_GEMM_LOG");
+      v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+  }
+  void begin(hipStream_t s) {
+    if (!on()) return;
+    stream = s;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+  }
+  void end(const char* kind, long M, long N, long K, int taps, int inst, const char* variant, double flops) {
+    if (!on() || !e0) return;
+    (void)hipEventRecord(e1, stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    fprintf(stderr, "FTGEMM %s M=%ld N=%ld K=%ld taps=%d inst=%d %s us=%.1f TF=%.1f\n", kind, M, N, K, taps, inst,
+            variant, ms * 1e3, flops / (ms * 1e-3) / 1e12);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+};
+
 }  // namespace
 
 size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& t) {
@@ -445,6 +478,8 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
     else                                                                                                       \
       hipLaunchKernelGGL((ft_gemm_rows_kernel<TM_, TM_, BNC_, false>), grid, dim3(256), 0, stream, *batch);    \
   } while (0)
+  GemmLog log;
+  log.begin(stream);
   if (big) {
     if (b_ncontig) FT_ROWS_LAUNCH(2, true);
     else FT_ROWS_LAUNCH(2, false);
@@ -453,6 +488,16 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
     else FT_ROWS_LAUNCH(1, false);
   }
 #undef FT_ROWS_LAUNCH
+  if (GemmLog::on()) {
+    double fl = 0;
+    long sk = 0;
+    for (int i = 0; i < ntasks; ++i) {
+      const FtGemmTask& t = batch->t[i];
+      fl += 2.0 * t.M * t.N * t.K * t.taps * t.nz;
+      sk += (long)t.K * t.taps;
+    }
+    log.end(b_ncontig ? "rowsNN" : "rowsNT", maxM, maxN, sk, ntasks, batch->t[0].nz, big ? "128" : "64", fl);
+  }
   return ft_check_launch("gemm_rows");
 }
 
@@ -476,6 +521,8 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   dim3 grid(ft_cdiv(t.M, bm), ft_cdiv(t.N, bm), p.S * t.taps * t.nz);
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_tn: grid too large");
   const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
+  GemmLog log;
+  log.begin(stream);
   if (p.tm == 2) {
     if (fast) hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
     else hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
@@ -488,5 +535,10 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   long total = (long)t.nz * t.taps * t.M * t.N;
   hipLaunchKernelGGL(ft_splitk_reduce_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, stream, workspace, t.dst,
                      t.M, t.N, t.taps, p.S, t.ldm, t.ldn, t.ldj, t.accumulate, t.nz, t.nz1, t.sD0, t.sD1);
+  if (GemmLog::on()) {
+    char var[32];
+    snprintf(var, sizeof(var), "%d/S%d", 64 * p.tm, p.S);
+    log.end("tn", t.M, t.N, t.R, t.taps, t.nz, var, 2.0 * t.M * t.N * t.R * t.taps * t.nz);
+  }
   return ft_check_launch("splitk_reduce");
 }
