@@ -109,53 +109,77 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
   const int tid = threadIdx.x;
   const int kq = tid & 7, rr = tid >> 3;      // K-contiguous staging: 8 float4 along K, 32 rows / pass
 
-  // row map for this thread's A rows
+  // Every task field the K loop needs is copied into a local FIRST: left as T.x the compiler re-reads them with
+  // s_load inside the loop, and each such read costs an `s_waitcnt lgkmcnt(0)` that also drains the LDS operand
+  // prefetch (SMEM and LDS share the counter).
+  const int tM = T.M, tN = T.N, tK = T.K;
+  const long lda = T.lda, ldb = T.ldb, btap = T.b_tap_stride;
+  const int Tlog = T.amap.Tlog, Tvalid = T.amap.Tvalid, shift0 = T.amap.shift0, sstep = T.amap.shift_step;
+  const long abst = T.amap.bstride, atst = T.amap.tstride;
+  const bool avec = T.a_vec, bvec = T.b_vec;
+
+  // row map for this thread's A rows: logical row -> (item, t); the pointer of (item, t + 0) is kept, a tap only adds
+  // a wave-uniform offset and a range test
   int a_t[PA];
-  long a_base[PA];
   bool a_ok[PA];
+  const float* a_row[PA];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
     int m = m0 + rr + 32 * p;
-    a_ok[p] = m < T.M;
-    int b = m / T.amap.Tlog;
-    a_t[p] = m - b * T.amap.Tlog;
-    a_base[p] = (long)b * T.amap.bstride;
+    a_ok[p] = m < tM;
+    int b = m / Tlog;
+    a_t[p] = m - b * Tlog;
+    a_row[p] = TA + ((long)b * abst + (long)a_t[p] * atst) * lda + 4 * kq;
   }
-  const int kch = (T.K + BK - 1) / BK;
+  // B rows (NT) / B k-rows (NN) of this thread
+  constexpr int NQ = BN / 4;                  // NN: float4 per k-row
+  constexpr int KR = 256 / NQ;                // NN: k-rows per pass
+  const int nq = tid % NQ, kr = tid / NQ;
+  const float* b_row[PB];
+  bool b_ok[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    if constexpr (!BNC) {
+      const int n = n0 + rr + 32 * p;
+      b_ok[p] = n < tN;
+      b_row[p] = TB + (long)n * ldb + 4 * kq;
+    } else {
+      b_ok[p] = n0 + 4 * nq < tN;
+      b_row[p] = TB + (long)(kr + KR * p) * ldb + n0 + 4 * nq;
+    }
+  }
+  const int kch = (tK + BK - 1) / BK;
   const int nch = T.taps * kch;
 
   float4 ra[PA], rb[PB];
   auto load_stage = [&](int c) {
     const int j = c / kch;
     const int k0 = (c - j * kch) * BK;
-    const int shift = T.amap.shift0 + j * T.amap.shift_step;
+    const int shift = shift0 + j * sstep;
     const int k = k0 + 4 * kq;
+    const bool kok = k < tK;
+    const long aoff = (long)shift * atst * lda + k0;           // wave-uniform
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      int ts = a_t[p] + shift;
-      bool ok = a_ok[p] && ts >= 0 && ts < T.amap.Tvalid;
-      const float* ptr = TA + (a_base[p] + (long)ts * T.amap.tstride) * T.lda + k;
-      if constexpr (FAST) ra[p] = ld4_sel(ptr, TA, ok && k < T.K);
-      else ra[p] = ld4(ptr, ok ? T.K - k : 0, T.a_vec);
+      const int ts = a_t[p] + shift;
+      const bool ok = a_ok[p] & (ts >= 0) & (ts < Tvalid);
+      if constexpr (FAST) ra[p] = ld4_sel(a_row[p] + aoff, TA, ok & kok);
+      else ra[p] = ld4(a_row[p] + aoff, ok ? tK - k : 0, avec);
     }
-    const float* Bj = TB + (long)j * T.b_tap_stride;
     if constexpr (!BNC) {
+      const long boff = (long)j * btap + k0;                   // wave-uniform
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
-        int n = n0 + rr + 32 * p;
-        if constexpr (FAST) rb[p] = ld4_sel(Bj + (long)n * T.ldb + k, Bj, n < T.N && k < T.K);
-        else rb[p] = ld4(Bj + (long)n * T.ldb + k, n < T.N ? T.K - k : 0, T.b_vec);
+        if constexpr (FAST) rb[p] = ld4_sel(b_row[p] + boff, TB, b_ok[p] & kok);
+        else rb[p] = ld4(b_row[p] + boff, b_ok[p] ? tK - k : 0, bvec);
       }
     } else {
-      constexpr int NQ = BN / 4;              // float4 per k-row
-      constexpr int KR = 256 / NQ;            // k-rows per pass
-      const int nq = tid % NQ, kr = tid / NQ;
+      const long boff = (long)j * btap + (long)k0 * ldb;       // wave-uniform
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
-        int kk = k0 + kr + KR * p;
-        int n = n0 + 4 * nq;
-        if constexpr (FAST) rb[p] = ld4_sel(Bj + (long)kk * T.ldb + n, Bj, n < T.N && kk < T.K);
-        else rb[p] = ld4(Bj + (long)kk * T.ldb + n, kk < T.K ? T.N - n : 0, T.b_vec);
+        const int kk = k0 + kr + KR * p;
+        if constexpr (FAST) rb[p] = ld4_sel(b_row[p] + boff, TB, b_ok[p] & (kk < tK));
+        else rb[p] = ld4(b_row[p] + boff, kk < tK ? tN - (n0 + 4 * nq) : 0, bvec);
       }
     }
   };
@@ -217,29 +241,35 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
   }
 
   // epilogue: lane holds column l31, rows (e&3) + 8*(e>>2) + 4*half of each 32x32 tile
+  const float* ebias = T.bias;
+  const float* escale = T.scale;
+  const float* eshift = T.shift;
+  const bool erelu = T.relu != 0, eacc = T.accumulate != 0;
+  const long ldc = T.ldc, cbst = T.cmap.bstride, ctst = T.cmap.tstride;
+  const int cTlog = T.cmap.Tlog;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * 32 * TN + 32 * j + l31;
-      if (col >= T.N) continue;
-      const float bv = T.bias ? T.bias[col] : 0.f;
-      const float sc = T.scale ? T.scale[col] : 1.f;
-      const float sh = T.scale ? T.shift[col] : 0.f;
+      if (col >= tN) continue;
+      const float bv = ebias ? ebias[col] : 0.f;
+      const float sc = escale ? escale[col] : 1.f;
+      const float sh = escale ? eshift[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (row >= T.M) continue;
+        if (row >= tM) continue;
         long crow = row;
-        if (T.cmap.bstride != 0) {            // non-identity output layout (time-major); identity skips the division
-          const int cb = row / T.cmap.Tlog;
-          crow = (long)cb * T.cmap.bstride + (long)(row - cb * T.cmap.Tlog) * T.cmap.tstride;
+        if (cbst != 0) {                      // non-identity output layout (time-major); identity skips the division
+          const int cb = row / cTlog;
+          crow = (long)cb * cbst + (long)(row - cb * cTlog) * ctst;
         }
-        float* cp = TC + crow * T.ldc + col;
+        float* cp = TC + crow * ldc + col;
         float v = acc[i][j][e] + bv;
-        if (T.relu) v = fmaxf(v, 0.f);
-        if (T.scale) v = v * sc + sh;
-        if (T.accumulate) v += *cp;      // residual / gradient accumulation happens last
+        if (erelu) v = fmaxf(v, 0.f);
+        if (escale) v = v * sc + sh;
+        if (eacc) v += *cp;              // residual / gradient accumulation happens last
         *cp = v;
       }
     }
@@ -276,30 +306,62 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
   const int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
   const int ashift = T.amap.shift0 + tap * T.amap.shift_step;
 
+  // task fields as locals (see the rows kernel) and (item, t) of every staged row tracked incrementally: stages are
+  // requested in strictly increasing order, BK rows apart, so the per-row integer division happens once
+  const int tM = T.M, tN = T.N;
+  const long lda = T.lda, ldb = T.ldb;
+  const int aTlog = T.amap.Tlog, aTvalid = T.amap.Tvalid, bTlog = T.bmap.Tlog, bTvalid = T.bmap.Tvalid;
+  const long abst = T.amap.bstride, atst = T.amap.tstride, bbst = T.bmap.bstride, btst = T.bmap.tstride;
+  const bool avec = T.a_vec, bvec = T.b_vec;
+  const int am = m0 + 4 * aq, bn = n0 + 4 * bq;
+  const bool am_ok = am < tM, bn_ok = bn < tN;
+  int a_b[PA], a_t[PA], b_b[PB], b_t[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int r = r_begin + ar + AR * p;
+    a_b[p] = r / aTlog;
+    a_t[p] = r - a_b[p] * aTlog;
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) {
+    const int r = r_begin + br + BR * p;
+    b_b[p] = r / bTlog;
+    b_t[p] = r - b_b[p] * bTlog;
+  }
+  int r_next = r_begin;                       // first row of the stage the next load_stage call fetches
+
   float4 ra[PA], rb[PB];
   auto load_stage = [&](int r0) {
+    (void)r0;                                 // == r_next by construction
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      int r = r0 + ar + AR * p;
-      int b = r / T.amap.Tlog;
-      int ts = r - b * T.amap.Tlog + ashift;
-      bool ok = r < r_end && ts >= 0 && ts < T.amap.Tvalid;
-      int m = m0 + 4 * aq;
-      const float* ptr = TA + ((long)b * T.amap.bstride + (long)ts * T.amap.tstride) * T.lda + m;
-      if constexpr (FAST) ra[p] = ld4_sel(ptr, TA, ok && m < T.M);
-      else ra[p] = ld4(ptr, ok ? T.M - m : 0, T.a_vec);
+      const int r = r_next + ar + AR * p;
+      const int ts = a_t[p] + ashift;
+      const bool ok = (r < r_end) & (ts >= 0) & (ts < aTvalid);
+      const float* ptr = TA + ((long)a_b[p] * abst + (long)ts * atst) * lda + am;
+      if constexpr (FAST) ra[p] = ld4_sel(ptr, TA, ok & am_ok);
+      else ra[p] = ld4(ptr, ok ? tM - am : 0, avec);
+      a_t[p] += BK;
+      while (a_t[p] >= aTlog) {
+        a_t[p] -= aTlog;
+        ++a_b[p];
+      }
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      int r = r0 + br + BR * p;
-      int b = r / T.bmap.Tlog;
-      int ts = r - b * T.bmap.Tlog + bshift;
-      bool ok = r < r_end && ts >= 0 && ts < T.bmap.Tvalid;
-      int n = n0 + 4 * bq;
-      const float* ptr = TB + ((long)b * T.bmap.bstride + (long)ts * T.bmap.tstride) * T.ldb + n;
-      if constexpr (FAST) rb[p] = ld4_sel(ptr, TB, ok && n < T.N);
-      else rb[p] = ld4(ptr, ok ? T.N - n : 0, T.b_vec);
+      const int r = r_next + br + BR * p;
+      const int ts = b_t[p] + bshift;
+      const bool ok = (r < r_end) & (ts >= 0) & (ts < bTvalid);
+      const float* ptr = TB + ((long)b_b[p] * bbst + (long)ts * btst) * ldb + bn;
+      if constexpr (FAST) rb[p] = ld4_sel(ptr, TB, ok & bn_ok);
+      else rb[p] = ld4(ptr, ok ? tN - bn : 0, bvec);
+      b_t[p] += BK;
+      while (b_t[p] >= bTlog) {
+        b_t[p] -= bTlog;
+        ++b_b[p];
+      }
     }
+    r_next += BK;
   };
   auto store_stage = [&](int buf) {
     float* As = smem + buf * STAGE;

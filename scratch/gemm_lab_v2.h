@@ -1,0 +1,299 @@
+// lab variants (included by gemm_lab.hip under -DLAB_V2)
+//   k_il   : K-major LDS as the product kernel, but the staging work (LDS stores of stage c+1, global loads of stage
+//            c+2) is sliced between the MFMA groups instead of sitting in front of them
+//   k_mk   : [m][k] LDS rows of 36 floats: ONE ds_write_b128 per staged float4, ds_read_b32 operand fetch (2-way
+//            bank conflict), staging sliced between MFMA groups
+//   k_dma  : [m][k] rows of 32 floats filled by global_load_lds_dwordx4 (no VGPR staging, no ds_write), XOR-swizzled
+//            16-B chunks so the operand fetch stays 2-way conflicted at worst
+
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_il(const float* __restrict__ A, const float* __restrict__ B,
+                                            float* __restrict__ C, int M, int N, int K) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, LDA = BM + 1, LDB = BN + 1;
+  constexpr int STAGE = BK * LDA + BK * LDB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, kq = tid & 7, rr = tid >> 3;
+  const int nch = K / BK;
+  float4 ra[4], rb[4];
+  const float* Ag = A + (long)(m0 + rr) * K + 4 * kq;
+  const float* Bg = B + (long)(n0 + rr) * K + 4 * kq;
+  const long rs = 32L * K;
+  auto gload = [&](int c, int p) {      // p 0..3: A rows, 4..7: B rows
+    if (p < 4) ra[p] = *reinterpret_cast<const float4*>(Ag + p * rs + c * BK);
+    else rb[p - 4] = *reinterpret_cast<const float4*>(Bg + (p - 4) * rs + c * BK);
+  };
+  auto lstore = [&](int buf, int p) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BK * LDA;
+    if (p < 4) {
+      int m = rr + 32 * p;
+      As[(4 * kq + 0) * LDA + m] = ra[p].x;
+      As[(4 * kq + 1) * LDA + m] = ra[p].y;
+      As[(4 * kq + 2) * LDA + m] = ra[p].z;
+      As[(4 * kq + 3) * LDA + m] = ra[p].w;
+    } else {
+      int n = rr + 32 * (p - 4);
+      Bs[(4 * kq + 0) * LDB + n] = rb[p - 4].x;
+      Bs[(4 * kq + 1) * LDB + n] = rb[p - 4].y;
+      Bs[(4 * kq + 2) * LDB + n] = rb[p - 4].z;
+      Bs[(4 * kq + 3) * LDB + n] = rb[p - 4].w;
+    }
+  };
+  const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+  for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (int p = 0; p < 8; ++p) gload(0, p);
+  for (int p = 0; p < 8; ++p) lstore(0, p);
+  if (nch > 1)
+    for (int p = 0; p < 8; ++p) gload(1, p);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int cur = c & 1;
+    const bool st = c + 1 < nch, ld = c + 2 < nch;
+    const float* ap = smem + cur * STAGE + half * LDA + wm * 64 + l31;
+    const float* bp = smem + cur * STAGE + BK * LDA + half * LDB + wn * 64 + l31;
+    float a0[TM], b0[TN], a1[TM], b1[TN];
+    for (int i = 0; i < TM; ++i) a0[i] = ap[32 * i];
+    for (int j = 0; j < TN; ++j) b0[j] = bp[32 * j];
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ks += 2) {
+      const int g = ks / 2;          // 0..7: staging slice
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a1[i] = ap[2 * (ks + 1) * LDA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b1[j] = bp[2 * (ks + 1) * LDB + 32 * j];
+      if (st) lstore(cur ^ 1, g);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = ap[2 * (ks + 2) * LDA + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = bp[2 * (ks + 2) * LDB + 32 * j];
+      }
+      if (ld) gload(c + 2, g);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 64 + 32 * j + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        C[(long)row * N + col] = acc[i][j][e];
+      }
+    }
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_mk(const float* __restrict__ A, const float* __restrict__ B,
+                                            float* __restrict__ C, int M, int N, int K) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, LR = 36;
+  constexpr int STAGE = (BM + BN) * LR;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, kq = tid & 7, rr = tid >> 3;
+  const int nch = K / BK;
+  float4 ra[4], rb[4];
+  const float* Ag = A + (long)(m0 + rr) * K + 4 * kq;
+  const float* Bg = B + (long)(n0 + rr) * K + 4 * kq;
+  const long rs = 32L * K;
+  auto gload = [&](int c, int p) {
+    if (p < 4) ra[p] = *reinterpret_cast<const float4*>(Ag + p * rs + c * BK);
+    else rb[p - 4] = *reinterpret_cast<const float4*>(Bg + (p - 4) * rs + c * BK);
+  };
+  auto lstore = [&](int buf, int p) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BM * LR;
+    if (p < 4) *reinterpret_cast<float4*>(As + (rr + 32 * p) * LR + 4 * kq) = ra[p];
+    else *reinterpret_cast<float4*>(Bs + (rr + 32 * (p - 4)) * LR + 4 * kq) = rb[p - 4];
+  };
+  const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+  for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (int p = 0; p < 8; ++p) gload(0, p);
+  for (int p = 0; p < 8; ++p) lstore(0, p);
+  if (nch > 1)
+    for (int p = 0; p < 8; ++p) gload(1, p);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int cur = c & 1;
+    const bool st = c + 1 < nch, ld = c + 2 < nch;
+    const float* ap = smem + cur * STAGE + (wm * 64 + l31) * LR + half;
+    const float* bp = smem + cur * STAGE + BM * LR + (wn * 64 + l31) * LR + half;
+    float a0[TM], b0[TN], a1[TM], b1[TN];
+    for (int i = 0; i < TM; ++i) a0[i] = ap[32 * i * LR];
+    for (int j = 0; j < TN; ++j) b0[j] = bp[32 * j * LR];
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ks += 2) {
+      const int g = ks / 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a1[i] = ap[32 * i * LR + 2 * (ks + 1)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b1[j] = bp[32 * j * LR + 2 * (ks + 1)];
+      if (st) lstore(cur ^ 1, g);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = ap[32 * i * LR + 2 * (ks + 2)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = bp[32 * j * LR + 2 * (ks + 2)];
+      }
+      if (ld) gload(c + 2, g);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 64 + 32 * j + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        C[(long)row * N + col] = acc[i][j][e];
+      }
+    }
+}
+
+// direct-to-LDS: stage = A rows [128][32] + B rows [128][32] floats, unpadded; chunk (16 B) c of row r is stored at
+// position c ^ (r & 7).  One global_load_lds_dwordx4 per wave fills 8 rows (1 KB); a stage = 32 KB = 32 such
+// instructions per workgroup = 8 per wave.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_dma(const float* __restrict__ A, const float* __restrict__ B,
+                                             float* __restrict__ C, int M, int N, int K) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128;
+  constexpr int STAGE = (BM + BN) * BK;          // floats
+  __shared__ __attribute__((aligned(1024))) float smem[2 * STAGE];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int nch = K / BK;
+  // this lane's part of a wave-wide 1-KB fill: row lr = lane>>3 (of 8), LDS chunk lc = lane&7 <- global chunk lc^lr
+  const int lr = lane >> 3, lc = lane & 7;
+  const int gch = lc ^ lr;                       // (row & 7) == lr because fills start at multiples of 8 rows
+  // wave w fills rows [32w, 32w+32) of A and of B: 4 + 4 instructions per stage
+  const float* Ag = A + (long)(m0 + 32 * wave + lr) * K + 4 * gch;
+  const float* Bg = B + (long)(n0 + 32 * wave + lr) * K + 4 * gch;
+  const long rs8 = 8L * K;
+  auto fill = [&](int c, int buf, int p) {       // p 0..3: A row blocks, 4..7: B row blocks
+    float* dst = smem + buf * STAGE + (p < 4 ? 0 : BM * BK) + (32 * wave + 8 * (p & 3)) * BK;
+    const float* src = (p < 4 ? Ag : Bg) + (p & 3) * rs8 + c * BK;
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  f32x16 acc[TM][TN];
+  for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j)
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (int p = 0; p < 8; ++p) fill(0, 0, p);
+  // operand addressing: row r = wm*64 + 32 i + l31 ; k = 2 ks + half -> chunk (k>>2) ^ (r&7), slot k&3
+  const int rA = wm * 64 + l31, rB = wn * 64 + l31;
+  const int swz = l31 & 7;                       // rows of this lane differ by multiples of 32: same r&7
+  for (int c = 0; c < nch; ++c) {
+    const int cur = c & 1;
+    // stage c must have landed (own fills) and be visible to all waves; the barrier also says that every wave is done
+    // with stage c-1, whose buffer the fills issued below overwrite
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool ld = c + 1 < nch;
+    const float* As = smem + cur * STAGE;
+    const float* Bs = As + BM * BK;
+    auto aop = [&](int i, int k) { return As[(rA + 32 * i) * BK + ((((k >> 2) ^ swz)) << 2) + (k & 3)]; };
+    auto bop = [&](int j, int k) { return Bs[(rB + 32 * j) * BK + ((((k >> 2) ^ swz)) << 2) + (k & 3)]; };
+    float a0[TM], b0[TN], a1[TM], b1[TN];
+    for (int i = 0; i < TM; ++i) a0[i] = aop(i, half);
+    for (int j = 0; j < TN; ++j) b0[j] = bop(j, half);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ks += 2) {
+      const int g = ks / 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a1[i] = aop(i, 2 * (ks + 1) + half);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b1[j] = bop(j, 2 * (ks + 1) + half);
+      if (ld) fill(c + 1, cur ^ 1, g);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = aop(i, 2 * (ks + 2) + half);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[j] = bop(j, 2 * (ks + 2) + half);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 64 + 32 * j + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        C[(long)row * N + col] = acc[i][j][e];
+      }
+    }
+}
+
+static double checksum(const float* C, int M, int N) {
+  std::vector<float> h((size_t)M * N);
+  (void)hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+  double s = 0;
+  for (size_t i = 0; i < h.size(); i += 997) s += h[i] * (double)((i % 13) + 1);
+  return s;
+}
+
+static void lab_v2(const float* A, const float* B, float* C, int M, int N, int K, double fl, const std::vector<float>&,
+                   const std::vector<float>&) {
+  dim3 grid(M / 128, N / 128);
+  hipLaunchKernelGGL(k_base<0>, grid, dim3(256), 0, 0, A, B, C, M, N, K);
+  (void)hipDeviceSynchronize();
+  const double ref = checksum(C, M, N);
+  (void)hipMemset(C, 0, (size_t)M * N * 4);
+  printf("interleaved     : %.1f TF", tf([&] { hipLaunchKernelGGL(k_il<0>, grid, dim3(256), 0, 0, A, B, C, M, N, K); }, fl));
+  printf("   checksum %s\n", checksum(C, M, N) == ref ? "ok" : "MISMATCH");
+  (void)hipMemset(C, 0, (size_t)M * N * 4);
+  printf("[m][k] b128     : %.1f TF", tf([&] { hipLaunchKernelGGL(k_mk<0>, grid, dim3(256), 0, 0, A, B, C, M, N, K); }, fl));
+  printf("   checksum %s\n", checksum(C, M, N) == ref ? "ok" : "MISMATCH");
+  (void)hipMemset(C, 0, (size_t)M * N * 4);
+  printf("direct-to-LDS   : %.1f TF", tf([&] { hipLaunchKernelGGL(k_dma<0>, grid, dim3(256), 0, 0, A, B, C, M, N, K); }, fl));
+  printf("   checksum %s\n", checksum(C, M, N) == ref ? "ok" : "MISMATCH");
+}
