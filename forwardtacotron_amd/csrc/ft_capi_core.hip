@@ -200,6 +200,30 @@ int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, l
   return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
 }
 
+// data gradient of the whole conv bank in ONE launch: dx[b,t,:] = sum_k sum_tap dy_k[b, t - tap + k/2, :] * W_k,tap
+// (K chained tasks accumulated in registers; member k's rows t >= Tvalid_k of dy are not part of its output)
+int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
+                          int C, int K, int Tbuf, void* stream) {
+  FT_REQUIRE(K >= 1 && K <= FT_MAX_TASKS, "conv_bank_bwd_data: K=%d unsupported (max %d)", K, FT_MAX_TASKS);
+  FT_REQUIRE(Tbuf == T || Tbuf == T + 1, "conv_bank_bwd_data: Tbuf must be T or T+1");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  long woff = 0;
+  for (int i = 0; i < K; ++i) {
+    const int k = i + 1;
+    FtGemmTask& t = b.t[i];
+    t.A = dy + (long)i * C; t.B = wp_all + woff; t.C = dx;
+    t.lda = lddy; t.ldb = Cin; t.ldc = lddx; t.b_tap_stride = (long)C * Cin;
+    t.M = B * T; t.N = Cin; t.K = C; t.taps = k;
+    const int Tvalid = (k % 2 == 0) ? Tbuf : T;            // even kernels produce T+1 rows when the buffer has them
+    FtRowMap m = {T > 0 ? T : 1, Tbuf, 1, Tvalid < Tbuf ? Tvalid : Tbuf, k / 2, -1};
+    t.amap = m;
+    woff += (long)k * C * Cin;
+  }
+  b.chain = K;
+  return ft_launch_gemm_rows(&b, K, true, (hipStream_t)stream);
+}
+
 static FtGemmTNTask conv_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T,
                                  int Cin, int Cout, int k, int Tbuf, int Tvalid) {
   FtGemmTNTask t;

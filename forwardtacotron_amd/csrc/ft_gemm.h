@@ -46,6 +46,9 @@ struct FtGemmTask {
 #define FT_MAX_TASKS 16
 struct FtGemmBatch {
   FtGemmTask t[FT_MAX_TASKS];
+  // chain > 1: tasks 0..chain-1 are ONE product, accumulated in registers: C = sum_i sum_tap shift(A_i) * B_i,tap with
+  // task 0's M, N, output and epilogue (conv-bank data gradient: every member adds into the same dx)
+  int chain;
 };
 
 // out_tap[m][n] = sum_r Amap(A)[r][m] * Bmap_tap(B)[r][n],  r over R logical rows   ("TN", split over rows)

@@ -109,52 +109,75 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
   const int tid = threadIdx.x;
   const int kq = tid & 7, rr = tid >> 3;      // K-contiguous staging: 8 float4 along K, 32 rows / pass
 
-  // Every task field the K loop needs is copied into a local FIRST: left as T.x the compiler re-reads them with
-  // s_load inside the loop, and each such read costs an `s_waitcnt lgkmcnt(0)` that also drains the LDS operand
-  // prefetch (SMEM and LDS share the counter).
-  const int tM = T.M, tN = T.N, tK = T.K;
-  const long lda = T.lda, ldb = T.ldb, btap = T.b_tap_stride;
-  const int Tlog = T.amap.Tlog, Tvalid = T.amap.Tvalid, shift0 = T.amap.shift0, sstep = T.amap.shift_step;
-  const long abst = T.amap.bstride, atst = T.amap.tstride;
-  const bool avec = T.a_vec, bvec = T.b_vec;
-
-  // row map for this thread's A rows: logical row -> (item, t); the pointer of (item, t + 0) is kept, a tap only adds
-  // a wave-uniform offset and a range test
+  // Every task field the K loop needs lives in a local: left as T.x the compiler re-reads them with s_load inside
+  // the loop, and each such read costs an `s_waitcnt lgkmcnt(0)` that also drains the LDS operand prefetch (SMEM and
+  // LDS share the counter).  The locals are re-filled when the loader moves on to the next task of a CHAIN
+  // (batch.chain tasks accumulate into task 0's output: C = sum_task sum_tap shift(A_task) * B_task,tap).
+  const int tM = T.M, tN = T.N;
+  const int nchain = batch.chain > 1 ? batch.chain : 1;
+  int tK, taps, Tvalid, shift0, sstep, kch;
+  long lda, ldb, btap, atst;
+  bool avec, bvec;
+  const float* curA;
+  const float* curB;
   int a_t[PA];
   bool a_ok[PA];
   const float* a_row[PA];
-#pragma unroll
-  for (int p = 0; p < PA; ++p) {
-    int m = m0 + rr + 32 * p;
-    a_ok[p] = m < tM;
-    int b = m / Tlog;
-    a_t[p] = m - b * Tlog;
-    a_row[p] = TA + ((long)b * abst + (long)a_t[p] * atst) * lda + 4 * kq;
-  }
-  // B rows (NT) / B k-rows (NN) of this thread
   constexpr int NQ = BN / 4;                  // NN: float4 per k-row
   constexpr int KR = 256 / NQ;                // NN: k-rows per pass
   const int nq = tid % NQ, kr = tid / NQ;
   const float* b_row[PB];
   bool b_ok[PB];
+  // row map of this thread's A rows: logical row -> (item, t); the pointer of (item, t + 0) is kept, a tap only adds a
+  // wave-uniform offset and a range test
+  auto setup = [&](const FtGemmTask& S, const float* SA, const float* SB) {
+    curA = SA;
+    curB = SB;
+    tK = S.K;
+    taps = S.taps;
+    lda = S.lda;
+    ldb = S.ldb;
+    btap = S.b_tap_stride;
+    Tvalid = S.amap.Tvalid;
+    shift0 = S.amap.shift0;
+    sstep = S.amap.shift_step;
+    atst = S.amap.tstride;
+    avec = S.a_vec;
+    bvec = S.b_vec;
+    kch = (tK + BK - 1) / BK;
+    const int Tlog = S.amap.Tlog;
+    const long abst = S.amap.bstride;
 #pragma unroll
-  for (int p = 0; p < PB; ++p) {
-    if constexpr (!BNC) {
-      const int n = n0 + rr + 32 * p;
-      b_ok[p] = n < tN;
-      b_row[p] = TB + (long)n * ldb + 4 * kq;
-    } else {
-      b_ok[p] = n0 + 4 * nq < tN;
-      b_row[p] = TB + (long)(kr + KR * p) * ldb + n0 + 4 * nq;
+    for (int p = 0; p < PA; ++p) {
+      int m = m0 + rr + 32 * p;
+      a_ok[p] = m < tM;
+      int b = m / Tlog;
+      a_t[p] = m - b * Tlog;
+      a_row[p] = SA + ((long)b * abst + (long)a_t[p] * atst) * lda + 4 * kq;
     }
-  }
-  const int kch = (tK + BK - 1) / BK;
-  const int nch = T.taps * kch;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      if constexpr (!BNC) {
+        const int n = n0 + rr + 32 * p;
+        b_ok[p] = n < tN;
+        b_row[p] = SB + (long)n * ldb + 4 * kq;
+      } else {
+        b_ok[p] = n0 + 4 * nq < tN;
+        b_row[p] = SB + (long)(kr + KR * p) * ldb + n0 + 4 * nq;
+      }
+    }
+  };
+  setup(T, TA, TB);
+  int nch = 0;                                // K stages of the whole chain
+  for (int i = 0; i < nchain; ++i) nch += batch.t[i].taps * ((batch.t[i].K + BK - 1) / BK);
+  if (nchain == 1) nch = taps * kch;
 
+  // loader cursor: (task, tap, k chunk) of the stage the next load_stage call fetches -- stages are requested in order
+  int l_task = 0, l_tap = 0, l_kc = 0;
   float4 ra[PA], rb[PB];
-  auto load_stage = [&](int c) {
-    const int j = c / kch;
-    const int k0 = (c - j * kch) * BK;
+  auto load_stage = [&](int) {
+    const int j = l_tap;
+    const int k0 = l_kc * BK;
     const int shift = shift0 + j * sstep;
     const int k = k0 + 4 * kq;
     const bool kok = k < tK;
@@ -163,14 +186,14 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
     for (int p = 0; p < PA; ++p) {
       const int ts = a_t[p] + shift;
       const bool ok = a_ok[p] & (ts >= 0) & (ts < Tvalid);
-      if constexpr (FAST) ra[p] = ld4_sel(a_row[p] + aoff, TA, ok & kok);
+      if constexpr (FAST) ra[p] = ld4_sel(a_row[p] + aoff, curA, ok & kok);
       else ra[p] = ld4(a_row[p] + aoff, ok ? tK - k : 0, avec);
     }
     if constexpr (!BNC) {
       const long boff = (long)j * btap + k0;                   // wave-uniform
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
-        if constexpr (FAST) rb[p] = ld4_sel(b_row[p] + boff, TB, b_ok[p] & kok);
+        if constexpr (FAST) rb[p] = ld4_sel(b_row[p] + boff, curB, b_ok[p] & kok);
         else rb[p] = ld4(b_row[p] + boff, b_ok[p] ? tK - k : 0, bvec);
       }
     } else {
@@ -178,8 +201,15 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
         const int kk = k0 + kr + KR * p;
-        if constexpr (FAST) rb[p] = ld4_sel(b_row[p] + boff, TB, b_ok[p] & (kk < tK));
+        if constexpr (FAST) rb[p] = ld4_sel(b_row[p] + boff, curB, b_ok[p] & (kk < tK));
         else rb[p] = ld4(b_row[p] + boff, kk < tK ? tN - (n0 + 4 * nq) : 0, bvec);
+      }
+    }
+    if (++l_kc == kch) {
+      l_kc = 0;
+      if (++l_tap == taps) {
+        l_tap = 0;
+        if (++l_task < nchain) setup(batch.t[l_task], batch.t[l_task].A, batch.t[l_task].B);
       }
     }
   };
@@ -524,9 +554,19 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   }
   if (maxM == 0 || maxN == 0) return FT_OK;
   for (int i = ntasks; i < FT_MAX_TASKS; ++i) batch->t[i] = batch->t[0];
+  const bool chained = batch->chain > 1;
+  if (chained) {
+    FT_REQUIRE(batch->chain == ntasks, "gemm_rows: chain must cover all tasks");
+    for (int i = 0; i < ntasks; ++i)
+      FT_REQUIRE(batch->t[i].M == batch->t[0].M && batch->t[i].N == batch->t[0].N && batch->t[i].nz == 1,
+                 "gemm_rows: chained tasks must share M and N");
+    tiles128 /= ntasks;
+  } else {
+    batch->chain = 0;
+  }
   const bool big = tiles128 >= 192 && maxN > 64 && maxM > 64;
   const int bm = big ? 128 : 64;
-  dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), ntasks == 1 ? batch->t[0].nz : ntasks);
+  dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), chained ? 1 : (ntasks == 1 ? batch->t[0].nz : ntasks));
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_rows: grid too large");
   bool fast = true;
   for (int i = 0; i < ntasks; ++i) {

@@ -189,6 +189,15 @@ def conv1d_bwd_data_raw(dy_ptr: int, lddy: int, wp: torch.Tensor, dx: torch.Tens
               int(accumulate), _stream())
 
 
+def conv_bank_bwd_data(dy: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, Cin: int, T: int) -> torch.Tensor:
+    """dy [B,Tbuf,K*C] (gradient of the bank buffer) -> dx [B,T,Cin], all K members in one chained launch"""
+    _chk(dy, 'dy'); _chk(wp_all, 'wp_all')
+    B, Tbuf, _ = dy.shape
+    dx = torch.empty(B, T, Cin, device=dy.device, dtype=dy.dtype)
+    _lib.call('ft_conv_bank_bwd_data', _p(dy), K * C, _p(wp_all), _p(dx), Cin, B, T, Cin, C, K, Tbuf, _stream())
+    return dx
+
+
 def conv1d_bwd_weight_raw(dy_ptr: int, lddy: int, x: torch.Tensor, dw: torch.Tensor, Tbuf: int, Tvalid: int) -> None:
     B, T, Cin = x.shape
     Cout, _, k = dw.shape

@@ -246,7 +246,7 @@ class ConvBankFn(Function):
         B, T, Cin = x.shape
         dz = H.maxpool2_bwd(_c(dout), z)
         dy, dgamma, dbeta = H.bn_bwd(dz, ybank, gamma, mean, rstd, group=C, relu=True)
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = H.conv_bank_bwd_data(dy, wp_all, K, C, Cin, T) if ctx.needs_input_grad[0] else None
         dws = []
         off = 0
         for i in range(K):
@@ -254,9 +254,6 @@ class ConvBankFn(Function):
             n = k * C * Cin
             Tvalid = T + (1 if k % 2 == 0 else 0)
             dptr = dy.data_ptr() + i * C * _F4
-            wp = wp_all[off:off + n].view(k, C, Cin)
-            if dx is not None:
-                H.conv1d_bwd_data_raw(dptr, K * C, wp, dx, B, T, T + 1, Tvalid, i > 0)
             dws.append(_emit(ws[i], lambda out, dptr=dptr, Tvalid=Tvalid: H.conv1d_bwd_weight_raw(
                 dptr, K * C, x, out, T + 1, Tvalid), (dy, x)))
             off += n

@@ -70,6 +70,10 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
 /* dx[b,t,ci] (+)= sum_j sum_co dy[b, t-j+k/2, co] * w[co,ci,j]; dy is [B,Tbuf,*] of which rows < Tvalid count */
 int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
                        int Cout, int k, int Tbuf, int Tvalid, int accumulate, void* stream);
+/* data gradient of the whole conv bank (backward of common_layers.py:97-102) in ONE launch: the K members' products
+ * are accumulated in registers into dx[B,T,Cin]; dy = [B,Tbuf,K*C] gradient of the bank buffer (Tbuf = T or T+1) */
+int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
+                          int C, int K, int Tbuf, void* stream);
 /* dw[co,ci,j] = sum_{b,t'<Tvalid} dy[b,t',co] * x[b,t'+j-k/2,ci]   (torch layout [Cout][Cin][k]) */
 size_t ft_conv1d_bwd_weight_workspace(int B, int T, int Cin, int Cout, int k, int Tvalid);
 int ft_conv1d_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T, int Cin,
