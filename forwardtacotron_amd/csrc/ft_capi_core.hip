@@ -104,6 +104,28 @@ int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, lo
   return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
 }
 
+// dx (+)= sum_i dy_i * w_i : several Linear layers that read the same input (highway W1/W2, the two directions of a
+// recurrence's input projection) hand their data gradients back in ONE chained launch
+int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
+                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream) {
+  FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_bwd_data_multi: ntasks %d out of range", ntasks);
+  if (check_tm("linear_bwd_data_multi", rows, dy_tm_B) || check_tm("linear_bwd_data_multi", rows, dx_tm_B))
+    return FT_ERR_ARG;
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < ntasks; ++i) {
+    FtGemmTask& t = b.t[i];
+    t.A = dy[i]; t.B = w[i]; t.C = dx;
+    t.lda = lddy; t.ldb = in_f; t.ldc = lddx;
+    t.M = rows; t.N = in_f; t.K = out_f; t.taps = 1;
+    t.amap = ft_rowmap_layout(rows, dy_tm_B);
+    t.cmap = ft_rowmap_layout(rows, dx_tm_B);
+    t.accumulate = accumulate;
+  }
+  b.chain = ntasks > 1 ? ntasks : 0;
+  return ft_launch_gemm_rows(&b, ntasks, true, (hipStream_t)stream);
+}
+
 static FtGemmTNTask linear_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int rows,
                                    int in_f, int out_f, int B, int T, int x_shift, int accumulate, int dy_tm,
                                    int x_tm) {

@@ -124,6 +124,17 @@ def linear_bwd_data_raw(dy_ptr: int, lddy: int, w: torch.Tensor, dx: torch.Tenso
               dy_tm_B, dx_tm_B, _stream())
 
 
+def linear_bwd_data_multi(dy_ptrs: Sequence[int], lddy: int, ws: Sequence[torch.Tensor], dx: torch.Tensor, rows: int,
+                          out_f: int, accumulate: bool = False, dy_tm_B: int = 0, dx_tm_B: int = 0) -> None:
+    """dx (+)= sum_i dy_i @ w_i in one chained launch (dy_i given as raw device addresses, common row stride)"""
+    n = len(ws)
+    in_f = ws[0].shape[1]
+    da = (ctypes.c_void_p * n)(*[int(p) for p in dy_ptrs])
+    wa = _ptr_array(ws)
+    _lib.call('ft_linear_bwd_data_multi', n, ctypes.cast(da, c_void_p), lddy, ctypes.cast(wa, c_void_p), _p(dx), in_f,
+              rows, in_f, out_f, int(accumulate), dy_tm_B, dx_tm_B, _stream())
+
+
 def linear_bwd_weight_raw(dy_ptr: int, lddy: int, x_ptr: int, ldx: int, dw: torch.Tensor, rows: int, in_f: int,
                           out_f: int, B: int = 1, T: int = 0, x_shift: int = 0, accumulate: bool = False,
                           dy_tm: bool = False, x_tm: bool = False) -> None:

@@ -303,8 +303,7 @@ class HighwayFn(Function):
         rows = x.numel() // C
         d12, dx = H.highway_gate_bwd(_c(dout), x12, x)
         p = d12.data_ptr()
-        H.linear_bwd_data_raw(p, 2 * C, w1, dx, rows, C, True)
-        H.linear_bwd_data_raw(p + C * _F4, 2 * C, w2, dx, rows, C, True)
+        H.linear_bwd_data_multi([p, p + C * _F4], 2 * C, [w1, w2], dx, rows, C, accumulate=True)
         dw1 = _emit(w1, lambda out: H.linear_bwd_weight_raw(p, 2 * C, x.data_ptr(), C, out, rows, C, C), (d12, x))
         dw2 = _emit(w2, lambda out: H.linear_bwd_weight_raw(p + C * _F4, 2 * C, x.data_ptr(), C, out, rows, C, C),
                     (d12, x))
@@ -326,12 +325,13 @@ def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx):
     dx = torch.empty_like(x) if need_dx else None
     dbx = H.colsum(dxp)                       # [2*G*H]
     dbh = dbx if dhp is dxp else H.colsum(dhp)
+    if dx is not None:          # both directions' input-projection data gradients in one chained launch
+        H.linear_bwd_data_multi([dxp.data_ptr(), dxp.data_ptr() + GH * _F4], 2 * GH, [params[0], params[4]], dx,
+                                rows, GH, dy_tm_B=B, dx_tm_B=0)
     for d in range(2):
         w_ih, w_hh, b_ih, b_hh = params[4 * d:4 * d + 4]
         px = dxp.data_ptr() + d * GH * _F4
         ph = dhp.data_ptr() + d * GH * _F4
-        if dx is not None:
-            H.linear_bwd_data_raw(px, 2 * GH, w_ih, dx, rows, GH, d > 0, dy_tm_B=B, dx_tm_B=0)
         g_ih = _emit(w_ih, lambda out, px=px: H.linear_bwd_weight_raw(
             px, 2 * GH, x.data_ptr(), I, out, rows, I, GH, B=B, T=T, dy_tm=True, x_tm=False), (dxp, x))
         g_hh = _emit(w_hh, lambda out, ph=ph, d=d: H.linear_bwd_weight_raw(

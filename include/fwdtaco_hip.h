@@ -70,6 +70,11 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
 /* dx[b,t,ci] (+)= sum_j sum_co dy[b, t-j+k/2, co] * w[co,ci,j]; dy is [B,Tbuf,*] of which rows < Tvalid count */
 int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
                        int Cout, int k, int Tbuf, int Tvalid, int accumulate, void* stream);
+/* dx (+)= sum_i dy_i[rows,out_f] * w_i[out_f,in_f]: the data gradients of several nn.Linear that read the same input
+ * (HighwayNetwork W1/W2, common_layers.py:35-40; the two directions' W_ih of nn.GRU / nn.LSTM) in ONE launch,
+ * accumulated in registers.  dy / w: host arrays of ntasks device pointers (ntasks <= 16). */
+int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
+                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream);
 /* data gradient of the whole conv bank (backward of common_layers.py:97-102) in ONE launch: the K members' products
  * are accumulated in registers into dx[B,T,Cin]; dy = [B,Tbuf,K*C] gradient of the bank buffer (Tbuf = T or T+1) */
 int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
