@@ -236,6 +236,64 @@ __global__ __launch_bounds__(256) void ft_bn_bwd_apply_kernel(const float* __res
   dy[idx] = r;
 }
 
+// 16-B-lane forms of the two kernels above (C % 4 == 0, group % 4 == 0, 16-B aligned buffers): one thread = 4 channels
+__global__ __launch_bounds__(256) void ft_bn_apply4_kernel(const float4* __restrict__ y, const float4* __restrict__ mean,
+                                                           const float4* __restrict__ rstd,
+                                                           const float4* __restrict__ gamma,
+                                                           const float4* __restrict__ beta,
+                                                           const float4* __restrict__ residual, float4* __restrict__ out,
+                                                           long total4, int Tbuf, int Tout, int C4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c = (int)(idx % C4);
+  const long row = idx / C4;
+  const int b = (int)(row / Tout), t = (int)(row - (long)b * Tout);
+  const float4 v = y[((long)b * Tbuf + t) * C4 + c];
+  const float4 mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  float4 o;
+  o.x = (v.x - mu.x) * rs.x * ga.x + be.x;
+  o.y = (v.y - mu.y) * rs.y * ga.y + be.y;
+  o.z = (v.z - mu.z) * rs.z * ga.z + be.z;
+  o.w = (v.w - mu.w) * rs.w * ga.w + be.w;
+  if (residual) {
+    const float4 r = residual[idx];
+    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+  }
+  out[idx] = o;
+}
+
+__global__ __launch_bounds__(256) void ft_bn_bwd_apply4_kernel(const float4* __restrict__ dout, const float4* __restrict__ y,
+                                                               const float4* __restrict__ mean,
+                                                               const float4* __restrict__ rstd,
+                                                               const float4* __restrict__ gamma,
+                                                               const float4* __restrict__ dgamma,
+                                                               const float4* __restrict__ dbeta, float4* __restrict__ dy,
+                                                               long total4, int B, int Tbuf, int Tout, int C4, int group,
+                                                               int relu) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c = (int)(idx % C4);
+  const long row = idx / C4;
+  const int b = (int)(row / Tbuf), t = (int)(row - (long)b * Tbuf);
+  const int tv = tvalid_of(4 * c, Tbuf, group);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t < tv) {
+    const float4 v = y[idx];
+    const float4 g = t < Tout ? dout[((long)b * Tout + t) * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float inv_n = 1.0f / ((float)B * (float)tv);
+    const float4 mu = mean[c], rs = rstd[c], ga = gamma[c], dg = dgamma[c], db = dbeta[c];
+#define FT_BN_BWD1(f)                                                                \
+  {                                                                                  \
+    const float xh = (v.f - mu.f) * rs.f;                                            \
+    r.f = ga.f * rs.f * (g.f - db.f * inv_n - xh * dg.f * inv_n);                    \
+    if (relu && !(v.f > 0.f)) r.f = 0.f;                                             \
+  }
+    FT_BN_BWD1(x) FT_BN_BWD1(y) FT_BN_BWD1(z) FT_BN_BWD1(w)
+#undef FT_BN_BWD1
+  }
+  dy[idx] = r;
+}
+
 // eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale
 __global__ void ft_bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                   float* scale, float* shift, int C) {
@@ -244,6 +302,11 @@ __global__ void ft_bn_fold_kernel(const float* gamma, const float* beta, const f
   float s = gamma[c] / sqrtf(rv[c] + eps);
   scale[c] = s;
   shift[c] = beta[c] - rm[c] * s;
+}
+
+template <typename... P>
+bool all16(P... ptrs) {
+  return (((uintptr_t)(const void*)ptrs % 16 == 0) && ...);
 }
 
 struct ChunkPlan {
@@ -292,8 +355,13 @@ int ft_bn_train_fwd(const float* y, const float* gamma, const float* beta, const
                      save_mean, save_rstd);
   if (out && Tout > 0) {
     long total = (long)B * Tout * C;
-    hipLaunchKernelGGL(ft_bn_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, y, save_mean, save_rstd, gamma,
-                       beta, residual, out, B, Tbuf, Tout, C);
+    if (C % 4 == 0 && all16(y, save_mean, save_rstd, gamma, beta, residual, out))
+      hipLaunchKernelGGL(ft_bn_apply4_kernel, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, s, (const float4*)y,
+                         (const float4*)save_mean, (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta,
+                         (const float4*)residual, (float4*)out, total / 4, Tbuf, Tout, C / 4);
+    else
+      hipLaunchKernelGGL(ft_bn_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, y, save_mean, save_rstd, gamma,
+                         beta, residual, out, B, Tbuf, Tout, C);
   }
   return ft_check_launch("bn_train_fwd");
 }
@@ -310,8 +378,14 @@ int ft_bn_bwd(const float* dout, const float* y, const float* gamma, const float
   hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, C, dbeta, dgamma, 1.0f, 0);
   long total = (long)B * Tbuf * C;
-  hipLaunchKernelGGL(ft_bn_bwd_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, dout, y, save_mean, save_rstd,
-                     gamma, dgamma, dbeta, dy, B, Tbuf, Tout, C, group, relu);
+  if (C % 4 == 0 && (group == 0 || group % 4 == 0) && all16(dout, y, save_mean, save_rstd, gamma, dgamma, dbeta, dy))
+    hipLaunchKernelGGL(ft_bn_bwd_apply4_kernel, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, s, (const float4*)dout,
+                       (const float4*)y, (const float4*)save_mean, (const float4*)save_rstd, (const float4*)gamma,
+                       (const float4*)dgamma, (const float4*)dbeta, (float4*)dy, total / 4, B, Tbuf, Tout, C / 4, group,
+                       relu);
+  else
+    hipLaunchKernelGGL(ft_bn_bwd_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, dout, y, save_mean, save_rstd,
+                       gamma, dgamma, dbeta, dy, B, Tbuf, Tout, C, group, relu);
   return ft_check_launch("bn_bwd");
 }
 

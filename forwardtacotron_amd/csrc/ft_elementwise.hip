@@ -103,6 +103,23 @@ __global__ void ft_maxpool_fwd_kernel(const float* __restrict__ x, float* __rest
   }
   out[i] = v;
 }
+// 16-B lanes (C % 4 == 0, 16-B aligned): one thread = 4 channels of one (b, t) row
+__global__ __launch_bounds__(256) void ft_maxpool_fwd4_kernel(const float4* __restrict__ x, float4* __restrict__ out,
+                                                              long total4, int T, int C4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const long row = i / C4;
+  const int t = (int)(row % T);
+  float4 v = x[i];
+  if (t > 0) {
+    const float4 p = x[i - C4];
+    v.x = v.x > p.x ? v.x : p.x;
+    v.y = v.y > p.y ? v.y : p.y;
+    v.z = v.z > p.z ? v.z : p.z;
+    v.w = v.w > p.w ? v.w : p.w;
+  }
+  out[i] = v;
+}
 // torch's max_pool backward sends the gradient to the FIRST maximal element of the window (t-1 on ties)
 __global__ void ft_maxpool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                       float* __restrict__ dx, int B, int T, int C) {
@@ -115,6 +132,35 @@ __global__ void ft_maxpool_bwd_kernel(const float* __restrict__ dout, const floa
   float g = 0.f;
   if (t == 0 || v > x[i - C]) g += dout[i];            // window t picks x[t]
   if (t + 1 < T && !(x[i + C] > v)) g += dout[i + C];  // window t+1 picks x[t] (its first element)
+  dx[i] = g;
+}
+__global__ __launch_bounds__(256) void ft_maxpool_bwd4_kernel(const float4* __restrict__ dout,
+                                                              const float4* __restrict__ x, float4* __restrict__ dx,
+                                                              long total4, int T, int C4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const long row = i / C4;
+  const int t = (int)(row % T);
+  const float4 v = x[i];
+  const float4 d0 = dout[i];
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t == 0) {
+    g = d0;
+  } else {
+    const float4 p = x[i - C4];
+    g.x = v.x > p.x ? d0.x : 0.f;
+    g.y = v.y > p.y ? d0.y : 0.f;
+    g.z = v.z > p.z ? d0.z : 0.f;
+    g.w = v.w > p.w ? d0.w : 0.f;
+  }
+  if (t + 1 < T) {
+    const float4 n = x[i + C4];
+    const float4 d1 = dout[i + C4];
+    g.x += !(n.x > v.x) ? d1.x : 0.f;
+    g.y += !(n.y > v.y) ? d1.y : 0.f;
+    g.z += !(n.z > v.z) ? d1.z : 0.f;
+    g.w += !(n.w > v.w) ? d1.w : 0.f;
+  }
   dx[i] = g;
 }
 
@@ -412,16 +458,24 @@ int ft_highway_gate_bwd(const float* dout, const float* x12, const float* x, flo
 int ft_maxpool2_fwd(const float* x, float* out, int B, int T, int C, void* stream) {
   long total = (long)B * T * C;
   if (total <= 0) return FT_OK;
-  hipLaunchKernelGGL(ft_maxpool_fwd_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, B, T,
-                     C);
+  if (C % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0)
+    hipLaunchKernelGGL(ft_maxpool_fwd4_kernel, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (float4*)out, total / 4, T, C / 4);
+  else
+    hipLaunchKernelGGL(ft_maxpool_fwd_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, out, B,
+                       T, C);
   return ft_check_launch("maxpool2_fwd");
 }
 
 int ft_maxpool2_bwd(const float* dout, const float* x, float* dx, int B, int T, int C, void* stream) {
   long total = (long)B * T * C;
   if (total <= 0) return FT_OK;
-  hipLaunchKernelGGL(ft_maxpool_bwd_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, x, dx,
-                     B, T, C);
+  if (C % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dout % 16) == 0 && ((uintptr_t)dx % 16) == 0)
+    hipLaunchKernelGGL(ft_maxpool_bwd4_kernel, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dout, (const float4*)x, (float4*)dx, total / 4, T, C / 4);
+  else
+    hipLaunchKernelGGL(ft_maxpool_bwd_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, x,
+                       dx, B, T, C);
   return ft_check_launch("maxpool2_bwd");
 }
 

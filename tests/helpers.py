@@ -87,6 +87,20 @@ FULL_FP = dict(num_chars=135,
                postnet_layers=4, postnet_heads=2, postnet_fft=1024, postnet_dropout=0.1, n_mels=80)
 
 
+TINY_MFP = dict(num_chars=135,
+                durpred_d_model=8, durpred_n_heads=2, durpred_layers=1, durpred_d_fft=12, durpred_dropout=0.0,
+                pitch_d_model=8, pitch_n_heads=1, pitch_layers=1, pitch_d_fft=12, pitch_dropout=0.0,
+                pitch_strength=1.0,
+                energy_d_model=8, energy_n_heads=2, energy_layers=1, energy_d_fft=8, energy_dropout=0.0,
+                energy_strength=0.5,
+                pitch_cond_d_model=8, pitch_cond_n_heads=2, pitch_cond_layers=1, pitch_cond_d_fft=8,
+                pitch_cond_dropout=0.0, pitch_cond_output_dims=3,
+                d_model=16, conv1_kernel=3, conv2_kernel=1,
+                prenet_layers=1, prenet_heads=2, prenet_fft=24, prenet_dropout=0.0,
+                postnet_layers=2, postnet_heads=4, postnet_fft=20, postnet_dropout=0.0, n_mels=10,
+                speaker_emb_dims=8)
+
+
 def sinusoid_pe(d_model, max_len=5000):
     """The reference's deterministic `pe` buffer (common_layers.py:134-141), [max_len,1,d]."""
     import math
