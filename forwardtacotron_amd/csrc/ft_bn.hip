@@ -121,6 +121,89 @@ __global__ __launch_bounds__(256) void ft_colsum4_partial_kernel(const float* __
   }
 }
 
+// modes 0 / 1 with 16-B lanes (C % 4 == 0, group % 4 == 0, 16-B aligned buffers): same block shape as the kernel above
+template <int MODE>
+__global__ __launch_bounds__(256) void ft_col_partial4_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, int B, int Tbuf, int Tout,
+                                                              int C, int group, int rows_per_chunk,
+                                                              double* __restrict__ partial) {
+  __shared__ double red[2][16][65];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cq * 4;
+  const long rows = (long)B * Tbuf;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C) {
+    const int tv = tvalid_of(c, Tbuf, group);
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu;
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const float4*>(mean + c);
+      rs = *reinterpret_cast<const float4*>(rstd + c);
+    }
+    int bb[4], tt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long r = r0 + rl + 16 * u;
+      bb[u] = (int)(r / Tbuf);
+      tt[u] = (int)(r - (long)bb[u] * Tbuf);
+    }
+    for (long r = r0 + rl; r < r1; r += 64) {
+      float4 v[4], g[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long rr = r + 16 * u;
+        ok[u] = rr < r1 && tt[u] < tv && (MODE == 0 || tt[u] < Tout);
+        v[u] = ok[u] ? *reinterpret_cast<const float4*>(y + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1)
+          g[u] = ok[u] ? *reinterpret_cast<const float4*>(dout + ((long)bb[u] * Tout + tt[u]) * C + c)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (MODE == 0) {
+          s0[0] += (double)v[u].x; s1[0] += (double)v[u].x * (double)v[u].x;
+          s0[1] += (double)v[u].y; s1[1] += (double)v[u].y * (double)v[u].y;
+          s0[2] += (double)v[u].z; s1[2] += (double)v[u].z * (double)v[u].z;
+          s0[3] += (double)v[u].w; s1[3] += (double)v[u].w * (double)v[u].w;
+        } else if (ok[u]) {
+          s0[0] += (double)g[u].x; s1[0] += (double)g[u].x * (double)((v[u].x - mu.x) * rs.x);
+          s0[1] += (double)g[u].y; s1[1] += (double)g[u].y * (double)((v[u].y - mu.y) * rs.y);
+          s0[2] += (double)g[u].z; s1[2] += (double)g[u].z * (double)((v[u].z - mu.z) * rs.z);
+          s0[3] += (double)g[u].w; s1[3] += (double)g[u].w * (double)((v[u].w - mu.w) * rs.w);
+        }
+        tt[u] += 64;
+        while (tt[u] >= Tbuf) {
+          tt[u] -= Tbuf;
+          ++bb[u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][rl][cq * 4 + e] = s0[e];
+    red[1][rl][cq * 4 + e] = s1[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < C) {
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        a0 += red[0][i][threadIdx.x];
+        a1 += red[1][i][threadIdx.x];
+      }
+      partial[((long)blockIdx.y * C + cc) * 2 + 0] = a0;
+      partial[((long)blockIdx.y * C + cc) * 2 + 1] = a1;
+    }
+  }
+}
+
 // ordered two-level sum of the chunk partials of column c: 8 lanes take contiguous chunk ranges, lane 0 of the group
 // adds the 8 range sums in range order (deterministic; 8x shorter dependent chain than one serial loop)
 constexpr int FIN_PARTS = 8;
@@ -348,8 +431,12 @@ int ft_bn_train_fwd(const float* y, const float* gamma, const float* beta, const
   FT_REQUIRE(workspace && workspace_bytes >= ft_bn_workspace(B, Tbuf, C), "bn_train_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   ChunkPlan p = plan_chunks((long)B * Tbuf, C);
-  hipLaunchKernelGGL(ft_col_partial_kernel<0>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, nullptr,
-                     nullptr, nullptr, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
+  if (C % 4 == 0 && (group == 0 || group % 4 == 0) && all16(y))
+    hipLaunchKernelGGL(ft_col_partial4_kernel<0>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, nullptr, nullptr,
+                       nullptr, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
+  else
+    hipLaunchKernelGGL(ft_col_partial_kernel<0>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, nullptr,
+                       nullptr, nullptr, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
   hipLaunchKernelGGL(ft_bn_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, B, Tbuf, C, group, momentum, eps, running_mean, running_var, num_batches_tracked,
                      save_mean, save_rstd);
@@ -373,8 +460,12 @@ int ft_bn_bwd(const float* dout, const float* y, const float* gamma, const float
   FT_REQUIRE(workspace && workspace_bytes >= ft_bn_workspace(B, Tbuf, C), "bn_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   ChunkPlan p = plan_chunks((long)B * Tbuf, C);
-  hipLaunchKernelGGL(ft_col_partial_kernel<1>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, dout,
-                     save_mean, save_rstd, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
+  if (C % 4 == 0 && (group == 0 || group % 4 == 0) && all16(y, dout, save_mean, save_rstd))
+    hipLaunchKernelGGL(ft_col_partial4_kernel<1>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, dout, save_mean,
+                       save_rstd, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
+  else
+    hipLaunchKernelGGL(ft_col_partial_kernel<1>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, dout,
+                       save_mean, save_rstd, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace);
   hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, C, dbeta, dgamma, 1.0f, 0);
   long total = (long)B * Tbuf * C;

@@ -128,6 +128,31 @@ def test_loader_and_prefetcher_cpu():
 
 
 @pytest.mark.gpu
+def test_gta_feature_dump(tmp_path):
+    """train_forward.py:33-51: one <item_id>.npy per item = mel_post[:, :mel_len] of the eval forward."""
+    from forwardtacotron_amd.gta import create_gta_features
+    from forwardtacotron_amd.model import ForwardTacotron
+    from helpers import TINY
+    items = _dataset(n=10, seed=9)
+    for it in items:
+        it['mel'] = np.random.RandomState(it['mel_len']).randn(10, it['mel_len']).astype(np.float32)
+    coll = ForwardCollator(TacoCollator(1, pin_memory=True))
+    random.seed(2)
+    host = list(batches(items, [it['mel_len'] for it in items], 4, coll, bin_size=4))
+    torch.manual_seed(0)
+    model = ForwardTacotron(**TINY).cuda()
+    n = create_gta_features(model, host[:2], host[2:], tmp_path)
+    assert n == 10 and not model.training
+    for hb in host:
+        with torch.no_grad():
+            want = model({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in hb.items()})['mel_post'].cpu().numpy()
+        for j, item_id in enumerate(hb['item_id']):
+            got = np.load(tmp_path / f'{item_id}.npy', allow_pickle=False)
+            assert got.shape == (10, int(hb['mel_len'][j]))
+            assert np.array_equal(got, want[j][:, :int(hb['mel_len'][j])])
+
+
+@pytest.mark.gpu
 def test_prefetcher_gpu_pinned_async_and_feeds_the_step():
     from forwardtacotron_amd.model import ForwardTacotron
     from helpers import TINY
