@@ -114,6 +114,8 @@ class BucketedAllReduce:
         self.works = []
         self.armed = False
         self.streams = set()
+        self.seen = set()
+        self.comm_stream = None
         if self.world > 1:
             for j, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(j))
@@ -128,6 +130,12 @@ class BucketedAllReduce:
         backward kernels write the flat buffer directly)."""
         if not self.armed or self.world <= 1:
             return
+        # A parameter can be announced twice in one backward: by the gradient sink when its kernel is enqueued and
+        # again by autograd's post-accumulate hook (the engine still visits the leaf although the Function returned
+        # None for it).  Count each parameter once, or a bucket is launched before its last member is written.
+        if j in self.seen:
+            return
+        self.seen.add(j)
         if self.flat.grad.is_cuda:              # gradients may be produced on several streams
             self.streams.add(torch.cuda.current_stream(self.flat.grad.device))
         b = self.param_bucket[j]
@@ -141,14 +149,25 @@ class BucketedAllReduce:
         lo, hi = self.buckets[b]
         self.launched[b] = True
         if self.flat.grad.is_cuda:
-            cur = torch.cuda.current_stream(self.flat.grad.device)
-            for s in self.streams:              # the collective must see every producer stream's work
-                if s != cur:
-                    cur.wait_stream(s)
+            # The collective must see every producer stream's work, but the compute streams must NOT wait for each
+            # other here (that would serialise the weight-gradient side stream with the main backward once per
+            # bucket): a dedicated communication stream collects the dependencies and RCCL's stream chains off it.
+            dev = self.flat.grad.device
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=dev)
+            cs = self.comm_stream
+            cs.wait_stream(torch.cuda.current_stream(dev))
+            for s in self.streams:
+                cs.wait_stream(s)
+            with torch.cuda.stream(cs):
+                self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
+                                                  async_op=True))
+            return
         self.works.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
                                           async_op=True))
 
     def start(self) -> None:
+        self.seen = set()
         self.pending = list(self.bucket_size)
         self.launched = [False] * len(self.buckets)
         self.works = []

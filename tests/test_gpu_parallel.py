@@ -1,0 +1,96 @@
+"""The N>1 path of the REAL train step on the GPU: two ranks (both on cuda:0 -- the box has one card -- talking over
+gloo, which moves CUDA tensors through the host) run TrainStep with the gradient sink, the weight-gradient side stream
+and the bucketed all-reduce on its communication stream.  Checked against a single-process computation of the same
+thing: Adam on the clipped MEAN of the two ranks' gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import TINY, TRAIN_CFG, load_npz, sub
+
+pytestmark = pytest.mark.gpu
+LR = 1e-3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(rank):
+    from oracle.ft_oracle import synthetic_batch
+    return synthetic_batch(B=3, Tmax=9, n_mels=TINY['n_mels'], max_dur=5, seed=40 + rank)
+
+
+def _model():
+    from forwardtacotron_amd.model import ForwardTacotron
+    M = load_npz('tiny_model.npz')
+    m = ForwardTacotron(**TINY)
+    m.load_state_dict({k: torch.as_tensor(v) for k, v in sub(M, 'sd/').items()})
+    return m.cuda()
+
+
+def _worker(rank, world, port, bucket_bytes, q):
+    import torch.distributed as dist
+    from forwardtacotron_amd.trainer import TrainStep
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    m = _model()
+    ts = TrainStep(m, lr=LR, train_cfg=TRAIN_CFG, bucket_bytes=bucket_bytes)
+    out = ts.step({k: v.cuda() for k, v in _batch(rank).items()})
+    torch.cuda.synchronize()
+    # numpy: pickled by value (torch tensors would travel as shared-memory handles that die with this process)
+    q.put((rank, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, float(out['grad_norm']),
+           len(ts.reducer.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_bytes', [4096, 24 << 20])
+def test_train_step_world2_matches_mean_gradient(bucket_bytes):
+    from forwardtacotron_amd.trainer import TrainStep
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sd0 = {k: torch.from_numpy(v) for k, v in res[0][1].items()}
+    sd1 = {k: torch.from_numpy(v) for k, v in res[1][1].items()}
+    differ = [k for k in sd0 if sd0[k].dtype.is_floating_point and 'running_' not in k and not torch.equal(sd0[k], sd1[k])]
+    assert not differ, differ                                       # every rank applied the identical update
+    if bucket_bytes == 4096:
+        assert res[0][3] > 1                                        # really bucketed
+
+    # single process: raw gradients of each rank's batch (lr = 0 leaves the weights alone), then Adam on the mean
+    grads = []
+    for r in range(2):
+        m = _model()
+        ts = TrainStep(m, lr=0.0, train_cfg=TRAIN_CFG)
+        ts.step({k: v.cuda() for k, v in _batch(r).items()})
+        grads.append({n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()})
+    m = _model()
+    p0 = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
+    g = {n: 0.5 * (grads[0][n] + grads[1][n]) for n in p0}
+    norm = torch.sqrt(sum((v.double() ** 2).sum() for v in g.values())).float()
+    assert abs(float(norm) - res[0][2]) < 1e-4 * max(1.0, float(norm))
+    coef = min(1.0, TRAIN_CFG['clip_grad_norm'] / (float(norm) + 1e-6))
+    for n in p0:
+        gc = g[n] * coef
+        mhat = (0.1 * gc) / (1 - 0.9)
+        vhat = (0.001 * gc * gc) / (1 - 0.999)
+        want = p0[n] - LR * mhat / (vhat.sqrt() + 1e-8)
+        live = g[n].abs() > 1e-6
+        assert float((sd0[n][live] - want[live]).abs().max() if live.any() else 0.0) < 2e-5, n
