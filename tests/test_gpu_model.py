@@ -298,6 +298,68 @@ def test_reference_unit_test_shapes(ft):
     assert tuple(gen['pitch'].shape) == (1, 1, 10)
 
 
+def test_long_form_eval_vs_oracle(ft):
+    """BASELINE configs[4] in miniature: long items (160 tokens -> ~900 frames, ragged) through the eval /
+    mel-generation path; the recurrences run 900 dependent persistent steps.  HIP vs oracle on every output."""
+    model, ops, hip = ft
+    from oracle import ft_oracle as O
+    cfg = dict(TINY, rnn_dims=32, postnet_dims=16)              # H multiples of 16: persistent kernels
+    torch.manual_seed(21)
+    m = model.ForwardTacotron(**cfg).eval()
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    batch = O.synthetic_batch(B=3, Tmax=160, n_mels=cfg['n_mels'], max_dur=12, seed=8)
+    with torch.no_grad():
+        want, _ = O.forward(P, {k: v.clone() for k, v in batch.items()}, cfg, training=False)
+        got = m.cuda()(cuda_batch(batch))
+    hip.check_rnn_status()
+    assert int(batch['mel_len'].max()) > 800
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+        assert got[k].shape == want[k].shape, k
+        assert maxdiff(got[k].cpu(), want[k]) < 1e-4, k
+
+
+def test_full_size_properties(ft):
+    """The benchmark configuration itself (singlespeaker.yaml, bs=32, Tx=128, Tm=841): no oracle at this size, so the
+    size-independent properties -- padding value beyond mel_len is reproduced exactly, LengthRegulator output rows are
+    bit-exact copies, eval is deterministic, and the train step moves every parameter by at most lr (Adam, step 1)."""
+    model, ops, hip = ft
+    from forwardtacotron_amd import data
+    from forwardtacotron_amd.trainer import TrainStep
+    from forwardtacotron_amd import hip as H
+    torch.manual_seed(0)
+    m = model.ForwardTacotron(**data.SINGLESPEAKER_MODEL).cuda().eval()
+    batch = data.to_device(data.synthetic_batch(B=32, Tmax=128, n_mels=80, seed=0), 'cuda')
+    dur0 = batch['dur'].clone()
+    with torch.no_grad():
+        a = m(batch)
+        batch['dur'].copy_(dur0)
+        b = m(batch)
+    hip.check_rnn_status()
+    Tm = int(batch['mel_len'].max())
+    assert tuple(a['mel'].shape) == (32, 80, Tm + 1) and Tm == 841
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                                 # deterministic
+    assert bool((a['mel'][:, :, Tm:] == -11.5129).all()) and bool((a['mel_post'][:, :, Tm:] == -11.5129).all())
+    assert bool(torch.isfinite(a['mel_post']).all())
+    # LengthRegulator: frame f of item b is an exact copy of the token row it came from
+    x = torch.randn(32, 128, 512, device='cuda')
+    cum, total = H.lr_scan(dur0.clone())
+    y, src = H.lr_expand(x, cum, Tm, want_src=True)
+    bi = torch.arange(32, device='cuda').unsqueeze(1).expand(32, Tm)
+    valid = src >= 0
+    assert int(valid.sum()) == int(batch['mel_len'].sum()) == 19320
+    assert torch.equal(y[valid], x[bi[valid], src[valid].long()]) and float(y[~valid].abs().sum()) == 0.0
+    # one optimisation step: |delta| <= lr for every parameter (first Adam step), loss finite
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    ts = TrainStep(m, lr=1e-4, train_cfg=dict(data.SINGLESPEAKER_TRAIN))
+    batch['dur'].copy_(dur0)
+    out = ts.step(batch)
+    hip.check_rnn_status()
+    assert bool(torch.isfinite(out['loss'])) and float(out['grad_norm']) > 0
+    worst = max(float((p.detach() - before[n]).abs().max()) for n, p in m.named_parameters())
+    assert 0 < worst <= 1e-4 * 1.001
+
+
 def test_cpu_tensors_are_refused(ft):
     model, ops, hip = ft
     m = model.ForwardTacotron(**TINY)
