@@ -30,31 +30,21 @@ if ROOT not in sys.path:
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
-def dominant_kernel_roofline(device):
-    """Times the dominant GEMM-shaped launch of the step -- the postnet conv bank forward
-    (M = 32*842 rows, 8 members k=1..8, Cin 80 -> 256: 2*B*T*80*256*36 FLOP) -- with HIP events."""
-    from forwardtacotron_amd import hip as H
-    B, T, Cin, C, K = 32, 841, 80, 256, 8
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, T, Cin, generator=g).to(device)
-    wp_all = (torch.randn(C * Cin * K * (K + 1) // 2, generator=g) * 0.05).to(device)
-    for _ in range(3):
-        H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T + 1)
-    reps = 10
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    s.record()
-    for _ in range(reps):
-        H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T + 1)
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / reps
+BANK_SHAPE = (32, 841, 80, 256, 8)      # B, T, Cin, C, K of the postnet conv bank forward at the benchmark config
+
+
+def dominant_kernel_roofline(events):
+    """The dominant GEMM-shaped launch of the step -- the postnet conv bank forward, one ft_gemm_rows_kernel<2,2,NT>
+    launch (M = 32*842 rows, 8 members k=1..8, Cin 80 -> 256: 2*B*(T+1)*80*256*36 FLOP) -- timed LIVE: HIP events
+    recorded around that launch on its own stream inside every timed step (forwardtacotron_amd.hip.bank_probe)."""
+    B, T, Cin, C, K = BANK_SHAPE
+    ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
     flops = 2.0 * B * (T + 1) * Cin * C * (K * (K + 1) // 2)
     ach = flops / (ms * 1e-3) / 1e12
     return {'bound': 'mfma', 'kernel': 'ft_gemm_rows_kernel<2,2,NT> (postnet conv bank fwd)',
             'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
-            'launch_ms': round(ms, 4), 'flops_per_launch': flops}
+            'launch_ms': round(ms, 4), 'launches_timed': len(events), 'flops_per_launch': flops}
 
 
 def cpu_baseline(model_cfg, train_cfg):
@@ -114,6 +104,10 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    from forwardtacotron_amd import hip as _hip
+    probe = {'shape': BANK_SHAPE, 'events': []}
+    if rank == 0:
+        _hip.bank_probe = probe               # two event records per step: no synchronisation, no extra launches
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -137,14 +131,14 @@ def main():
     else:
         tot_frm, tot_tok = float(n_frm), float(n_tok)
     loss = float(out['loss'])
-    from forwardtacotron_amd import hip as _hip
+    _hip.bank_probe = None
     _hip.check_rnn_status()            # raises if a persistent recurrence hit its spin bound
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = tot_frm * args.steps / dt
         step_tflops = data.train_flops(tot_tok, tot_frm) / (dt / args.steps) / 1e12
-        roof = dominant_kernel_roofline(device)
+        roof = dominant_kernel_roofline(probe['events'])
         roof['step'] = {'algorithmic_tflops': round(step_tflops, 2),
                         'frac_of_f32_mfma_peak': round(step_tflops / (F32_MFMA_PEAK_TFLOPS * world), 4),
                         'flop_per_valid_frame': 64.5e6}
