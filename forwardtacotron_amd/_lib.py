@@ -94,6 +94,17 @@ def call(name: str, *args):
         raise FtError(f'{name}: {lib().ft_last_error().decode()}')
 
 
+_ws_cache = {}
+
+
 def query(name: str, *args):
-    """Call a value-returning entry point (workspace sizes)."""
+    """Call a value-returning entry point.  `*_workspace` size queries are pure functions of their integer arguments
+    and sit in front of most launches, so their answers are memoised."""
+    if name.endswith('_workspace'):
+        key = (name, args)
+        v = _ws_cache.get(key)
+        if v is None:
+            v = getattr(lib(), name)(*args)
+            _ws_cache[key] = v
+        return v
     return getattr(lib(), name)(*args)

@@ -18,7 +18,7 @@ from torch.autograd import Function
 from . import _lib
 from . import hip as H
 from . import ops
-from .model import LengthRegulator, NUM_CHARS_DEFAULT, PAD_VALUE, _dropout
+from .model import LengthRegulator, NUM_CHARS_DEFAULT, PAD_VALUE, _dropout, _seed
 from .ops import _c, _emit
 
 _F4 = 4
@@ -239,7 +239,7 @@ class FFTBlock(nn.Module):
     def forward(self, src: torch.Tensor, key_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
         a = self.self_attn
         p = self.p if self.training else 0.0
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        seed = _seed() if p > 0 else 0
         src2 = MHAFn.apply(src, key_pad, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
                            self.nhead, p, seed)
         src2 = _dropout(src2, self.p, self.training)

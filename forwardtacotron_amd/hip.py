@@ -18,7 +18,16 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device.  Goes straight to the C binding: the public
+    `torch.cuda.current_stream()` resolves the device through `torch.cuda.is_available()`, i.e. a device-count
+    query (~18 us on this stack) per call -- at ~300 launches per step that alone made the FastPitch step host-bound."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -21,9 +21,20 @@ PAD_VALUE = -11.5129
 NUM_CHARS_DEFAULT = 135      # len(utils.text.symbols.phonemes), utils/text/symbols.py:21-23
 
 
+_seed_state = {'torch_seed': None, 'base': 0, 'n': 0}
+
+
 def _seed() -> int:
-    # host RNG only (no device sync); follows torch.manual_seed
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    """Seed of one dropout site: host arithmetic only (no device sync, no tensor op -- a step draws ~170 of them).
+    The stream is re-based from torch's host RNG whenever torch.manual_seed() installs a different seed."""
+    st = _seed_state
+    s = torch.initial_seed()
+    if st['torch_seed'] != s:
+        st['torch_seed'] = s
+        st['base'] = int(torch.randint(0, 2 ** 62, (1,)).item())
+        st['n'] = 0
+    st['n'] += 1
+    return (st['base'] + 0x9E3779B97F4A7C15 * st['n']) & ((1 << 62) - 1)
 
 
 def _dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:

@@ -357,7 +357,7 @@ def test_full_size_properties(ft):
     hip.check_rnn_status()
     assert bool(torch.isfinite(out['loss'])) and float(out['grad_norm']) > 0
     worst = max(float((p.detach() - before[n]).abs().max()) for n, p in m.named_parameters())
-    assert 0 < worst <= 1e-4 * 1.001
+    assert 0 < worst <= 1e-4 * 1.01          # lr, plus the fp32 rounding of p - delta for |p| up to ~1
 
 
 def test_cpu_tensors_are_refused(ft):
