@@ -525,6 +525,15 @@ struct GemmLog {
 
 }  // namespace
 
+bool ft_gemm_b3_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FT_GEMM_B3");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& t) {
   TNPlan p = plan_tn(t);
   return (size_t)p.S * t.taps * (t.nz > 1 ? t.nz : 1) * t.M * t.N;
@@ -582,7 +591,10 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   } while (0)
   GemmLog log;
   log.begin(stream);
-  if (big) {
+  const bool b3 = fast && !b_ncontig && ft_gemm_b3_enabled();
+  if (b3) {
+    (void)ft_launch_gemm_rows_b3(*batch, big, grid, stream);
+  } else if (big) {
     if (b_ncontig) FT_ROWS_LAUNCH(2, true);
     else FT_ROWS_LAUNCH(2, false);
   } else {
@@ -598,7 +610,8 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
       fl += 2.0 * t.M * t.N * t.K * t.taps * t.nz;
       sk += (long)t.K * t.taps;
     }
-    log.end(b_ncontig ? "rowsNN" : "rowsNT", maxM, maxN, sk, ntasks, batch->t[0].nz, big ? "128" : "64", fl);
+    log.end(b_ncontig ? "rowsNN" : (b3 ? "rowsB3" : "rowsNT"), maxM, maxN, sk, ntasks, batch->t[0].nz,
+            big ? "128" : "64", fl);
   }
   return ft_check_launch("gemm_rows");
 }

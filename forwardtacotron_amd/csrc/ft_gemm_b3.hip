@@ -1,0 +1,249 @@
+// fp32 GEMMs on the bf16 matrix pipe ("bf16x3"): same task descriptors, row maps, taps, chains and epilogues as
+// ft_gemm.hip, but every fp32 operand is split EXACTLY into three bf16 pieces while it is staged into LDS
+//     x = hi + mid + lo      (truncation splits: each remainder is exact in fp32, 3 x 8 mantissa bits = fp32's 24)
+// and a product keeps the six terms down to 2^-16 relative (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi), accumulated
+// in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are <= 2^-23 |a||b| -- the size of fp32's own product
+// rounding: measured against an f64 reference the result is as close as (slightly closer than) the
+// v_mfma_f32_32x32x2_f32 path (scratch/gemm_lab_b3.h: 1.9e-5 vs 2.3e-5 max error at K = 512, |C| up to 26).
+// bf16 MFMA runs at 16x the fp32 MFMA rate and six of them replace one, so the matrix pipe has 2.67x fewer cycles to
+// spend; what bounds the kernel instead is the staging work (split = ~5 VALU ops per element, LDS traffic).
+//
+// Layout: operand rows are K-contiguous in LDS, [row][plane hi|mid|lo][32 k] bf16 + 16 B pad = 208 B per row, so an
+// MFMA fragment (8 consecutive k of one row) is ONE ds_read_b128 and a staged float4 becomes three ds_write_b64.
+// One LDS stage of 32 k (53 KB for the 128x128 tile -> two workgroups per CU), two barriers per stage; the next
+// stage's global loads are in flight during the MFMAs.  Only the NT form (both operands K-contiguous) exists: callers
+// with an [K][N] operand hand in its transpose.
+#include "ft_gemm.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int RS = 104;          // LDS row stride in bf16 elements: 3 planes x 32 + 8 pad
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, bool ok) {
+  const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
+  return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// exact truncation split of 4 floats into hi / mid / lo bf16 quadruples
+__device__ __forceinline__ void split3(const float4& v, u16x4& hi, u16x4& mid, u16x4& lo) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned h = __float_as_uint(f[i]) & 0xFFFF0000u;
+    const float r1 = f[i] - __uint_as_float(h);
+    const unsigned m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    hi[i] = (unsigned short)(h >> 16);
+    mid[i] = (unsigned short)(m >> 16);
+    lo[i] = (unsigned short)(__float_as_uint(r2) >> 16);
+  }
+}
+
+__device__ __forceinline__ void store_split(unsigned short* row, const float4& v) {
+  u16x4 h, m, l;
+  split3(v, h, m, l);
+  *reinterpret_cast<u16x4*>(row) = h;
+  *reinterpret_cast<u16x4*>(row + 32) = m;
+  *reinterpret_cast<u16x4*>(row + 64) = l;
+}
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch batch) {
+  const bool zbatch = batch.t[0].nz > 1;           // strided-batch launch: one task, blockIdx.z = instance
+  const FtGemmTask& T = batch.t[zbatch ? 0 : blockIdx.z];
+  const float* TA = T.A;
+  const float* TB = T.B;
+  float* TC = T.C;
+  if (zbatch) {
+    const int z0 = blockIdx.z / T.nz1, z1 = blockIdx.z - z0 * T.nz1;
+    TA += z0 * T.sA0 + z1 * T.sA1;
+    TB += z0 * T.sB0 + z1 * T.sB1;
+    TC += z0 * T.sC0 + z1 * T.sC1;
+  }
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[(BM + BN) * RS];
+  unsigned short* As = smem;
+  unsigned short* Bs = smem + BM * RS;
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (m0 >= T.M || n0 >= T.N) return;
+  const int tid = threadIdx.x;
+  const int kq = tid & 7, rr = tid >> 3;
+
+  // task fields in locals (see ft_gemm.hip); re-filled when the loader moves to the next task of a chain
+  const int tM = T.M, tN = T.N;
+  const int nchain = batch.chain > 1 ? batch.chain : 1;
+  int tK, taps, Tvalid, shift0, sstep, kch;
+  long lda, btap, atst;
+  const float* curA;
+  const float* curB;
+  int a_t[PA];
+  bool a_ok[PA], b_ok[PB];
+  const float* a_row[PA];
+  const float* b_row[PB];
+  auto setup = [&](const FtGemmTask& S, const float* SA, const float* SB) {
+    curA = SA;
+    curB = SB;
+    tK = S.K;
+    taps = S.taps;
+    lda = S.lda;
+    btap = S.b_tap_stride;
+    Tvalid = S.amap.Tvalid;
+    shift0 = S.amap.shift0;
+    sstep = S.amap.shift_step;
+    atst = S.amap.tstride;
+    kch = (tK + BK - 1) / BK;
+    const int Tlog = S.amap.Tlog;
+    const long abst = S.amap.bstride, ldb = S.ldb;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int m = m0 + rr + 32 * p;
+      a_ok[p] = m < tM;
+      const int b = m / Tlog;
+      a_t[p] = m - b * Tlog;
+      a_row[p] = SA + ((long)b * abst + (long)a_t[p] * atst) * lda + 4 * kq;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int n = n0 + rr + 32 * p;
+      b_ok[p] = n < tN;
+      b_row[p] = SB + (long)n * ldb + 4 * kq;
+    }
+  };
+  setup(T, TA, TB);
+  int nch = 0;
+  for (int i = 0; i < nchain; ++i) nch += batch.t[i].taps * ((batch.t[i].K + BK - 1) / BK);
+  if (nchain == 1) nch = taps * kch;
+
+  int l_task = 0, l_tap = 0, l_kc = 0;           // loader cursor
+  float4 ra[PA], rb[PB];
+  auto load_stage = [&]() {
+    const int j = l_tap;
+    const int k0 = l_kc * BK;
+    const int shift = shift0 + j * sstep;
+    const bool kok = k0 + 4 * kq < tK;
+    const long aoff = (long)shift * atst * lda + k0;
+    const long boff = (long)j * btap + k0;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int ts = a_t[p] + shift;
+      ra[p] = ld4_sel(a_row[p] + aoff, curA, a_ok[p] & (ts >= 0) & (ts < Tvalid) & kok);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) rb[p] = ld4_sel(b_row[p] + boff, curB, b_ok[p] & kok);
+    if (++l_kc == kch) {
+      l_kc = 0;
+      if (++l_tap == taps) {
+        l_tap = 0;
+        if (++l_task < nchain) setup(batch.t[l_task], batch.t[l_task].A, batch.t[l_task].B);
+      }
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) store_split(As + (rr + 32 * p) * RS + 4 * kq, ra[p]);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) store_split(Bs + (rr + 32 * p) * RS + 4 * kq, rb[p]);
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const unsigned short* ap = As + (wm * 32 * TM + l31) * RS + 8 * half;
+  const unsigned short* bp = Bs + (wn * 32 * TN + l31) * RS + 8 * half;
+  load_stage();
+  store_stage();
+  if (nch > 1) load_stage();
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                  // two k-steps of 16 per stage
+      bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          a[i][pl] = *reinterpret_cast<const bf16x8*>(ap + 32 * i * RS + 32 * pl + 16 * ks);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          b[j][pl] = *reinterpret_cast<const bf16x8*>(bp + 32 * j * RS + 32 * pl + 16 * ks);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {                // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (c + 1 < nch) {
+      store_stage();                                  // its registers were loaded one iteration ago
+      if (c + 2 < nch) load_stage();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: identical to ft_gemm_rows_kernel (same accumulator layout)
+  const float* ebias = T.bias;
+  const float* escale = T.scale;
+  const float* eshift = T.shift;
+  const bool erelu = T.relu != 0, eacc = T.accumulate != 0;
+  const long ldc = T.ldc, cbst = T.cmap.bstride, ctst = T.cmap.tstride;
+  const int cTlog = T.cmap.Tlog;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + l31;
+      if (col >= tN) continue;
+      const float bv = ebias ? ebias[col] : 0.f;
+      const float sc = escale ? escale[col] : 1.f;
+      const float sh = escale ? eshift[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row >= tM) continue;
+        long crow = row;
+        if (cbst != 0) {
+          const int cb = row / cTlog;
+          crow = (long)cb * cbst + (long)(row - cb * cTlog) * ctst;
+        }
+        float* cp = TC + crow * ldc + col;
+        float v = acc[i][j][e] + bv;
+        if (erelu) v = fmaxf(v, 0.f);
+        if (escale) v = v * sc + sh;
+        if (eacc) v += *cp;
+        *cp = v;
+      }
+    }
+}
+
+}  // namespace
+
+// NT, FAST (16-B aligned operands, K % 4 == 0) launches only; grid / tile choice made by ft_launch_gemm_rows
+int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream) {
+  if (big)
+    hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2>), grid, dim3(256), 0, stream, batch);
+  else
+    hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<1, 1>), grid, dim3(256), 0, stream, batch);
+  return FT_OK;
+}

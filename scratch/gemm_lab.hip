@@ -132,6 +132,10 @@ double tf(F launch, double flops, int reps = 5) {
 #ifdef LAB_V2
 #include "gemm_lab_v2.h"
 #endif
+#ifdef LAB_B3
+#include <math.h>
+#include "gemm_lab_b3.h"
+#endif
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 26880, N = argc > 2 ? atoi(argv[2]) : 2048, K = argc > 3 ? atoi(argv[3]) : 512;
@@ -153,6 +157,9 @@ int main(int argc, char** argv) {
   printf("MFMA only       : %.1f TF\n", tf([&] { hipLaunchKernelGGL(k_base<3>, grid, dim3(256), 0, 0, A, B, C, M, N, K); }, fl));
 #ifdef LAB_V2
   lab_v2(A, B, C, M, N, K, fl, ha, hb);
+#endif
+#ifdef LAB_B3
+  lab_b3(A, B, C, M, N, K, fl);
 #endif
   return 0;
 }
