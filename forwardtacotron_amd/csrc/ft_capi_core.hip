@@ -90,24 +90,25 @@ int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const
 }
 
 int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, long lddx, int rows, int in_f,
-                       int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream) {
+                       int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed, void* stream) {
   if (check_tm("linear_bwd_data", rows, dy_tm_B) || check_tm("linear_bwd_data", rows, dx_tm_B)) return FT_ERR_ARG;
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   FtGemmTask& t = b.t[0];
   t.A = dy; t.B = w; t.C = dx;
-  t.lda = lddy; t.ldb = in_f; t.ldc = lddx;
+  t.lda = lddy; t.ldb = w_transposed ? out_f : in_f; t.ldc = lddx;     // w^T [in_f][out_f]: both operands K-contiguous
   t.M = rows; t.N = in_f; t.K = out_f; t.taps = 1;
   t.amap = ft_rowmap_layout(rows, dy_tm_B);
   t.cmap = ft_rowmap_layout(rows, dx_tm_B);
   t.accumulate = accumulate;
-  return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
+  return ft_launch_gemm_rows(&b, 1, !w_transposed, (hipStream_t)stream);
 }
 
 // dx (+)= sum_i dy_i * w_i : several Linear layers that read the same input (highway W1/W2, the two directions of a
 // recurrence's input projection) hand their data gradients back in ONE chained launch
 int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
-                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream) {
+                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
+                             void* stream) {
   FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_bwd_data_multi: ntasks %d out of range", ntasks);
   if (check_tm("linear_bwd_data_multi", rows, dy_tm_B) || check_tm("linear_bwd_data_multi", rows, dx_tm_B))
     return FT_ERR_ARG;
@@ -116,14 +117,14 @@ int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, cons
   for (int i = 0; i < ntasks; ++i) {
     FtGemmTask& t = b.t[i];
     t.A = dy[i]; t.B = w[i]; t.C = dx;
-    t.lda = lddy; t.ldb = in_f; t.ldc = lddx;
+    t.lda = lddy; t.ldb = w_transposed ? out_f : in_f; t.ldc = lddx;
     t.M = rows; t.N = in_f; t.K = out_f; t.taps = 1;
     t.amap = ft_rowmap_layout(rows, dy_tm_B);
     t.cmap = ft_rowmap_layout(rows, dx_tm_B);
     t.accumulate = accumulate;
   }
   b.chain = ntasks > 1 ? ntasks : 0;
-  return ft_launch_gemm_rows(&b, ntasks, true, (hipStream_t)stream);
+  return ft_launch_gemm_rows(&b, ntasks, !w_transposed, (hipStream_t)stream);
 }
 
 static FtGemmTNTask linear_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int rows,
@@ -208,24 +209,24 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
 }
 
 int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
-                       int Cout, int k, int Tbuf, int Tvalid, int accumulate, void* stream) {
+                       int Cout, int k, int Tbuf, int Tvalid, int accumulate, int wp_transposed, void* stream) {
   FT_REQUIRE(k >= 1 && Tvalid <= Tbuf, "conv1d_bwd_data: bad k/Tvalid");
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   FtGemmTask& t = b.t[0];
   t.A = dy; t.B = wp; t.C = dx;
-  t.lda = lddy; t.ldb = Cin; t.ldc = lddx; t.b_tap_stride = (long)Cout * Cin;
+  t.lda = lddy; t.ldb = wp_transposed ? Cout : Cin; t.ldc = lddx; t.b_tap_stride = (long)Cout * Cin;
   t.M = B * T; t.N = Cin; t.K = Cout; t.taps = k;
   FtRowMap m = {T > 0 ? T : 1, Tbuf, 1, Tvalid, k / 2, -1};     // dy row = t - tap + pad
   t.amap = m;
   t.accumulate = accumulate;
-  return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
+  return ft_launch_gemm_rows(&b, 1, !wp_transposed, (hipStream_t)stream);
 }
 
 // data gradient of the whole conv bank in ONE launch: dx[b,t,:] = sum_k sum_tap dy_k[b, t - tap + k/2, :] * W_k,tap
 // (K chained tasks accumulated in registers; member k's rows t >= Tvalid_k of dy are not part of its output)
 int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
-                          int C, int K, int Tbuf, void* stream) {
+                          int C, int K, int Tbuf, int wp_transposed, void* stream) {
   FT_REQUIRE(K >= 1 && K <= FT_MAX_TASKS, "conv_bank_bwd_data: K=%d unsupported (max %d)", K, FT_MAX_TASKS);
   FT_REQUIRE(Tbuf == T || Tbuf == T + 1, "conv_bank_bwd_data: Tbuf must be T or T+1");
   FtGemmBatch b;
@@ -235,7 +236,7 @@ int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float
     const int k = i + 1;
     FtGemmTask& t = b.t[i];
     t.A = dy + (long)i * C; t.B = wp_all + woff; t.C = dx;
-    t.lda = lddy; t.ldb = Cin; t.ldc = lddx; t.b_tap_stride = (long)C * Cin;
+    t.lda = lddy; t.ldb = wp_transposed ? C : Cin; t.ldc = lddx; t.b_tap_stride = (long)C * Cin;
     t.M = B * T; t.N = Cin; t.K = C; t.taps = k;
     const int Tvalid = (k % 2 == 0) ? Tbuf : T;            // even kernels produce T+1 rows when the buffer has them
     FtRowMap m = {T > 0 ? T : 1, Tbuf, 1, Tvalid < Tbuf ? Tvalid : Tbuf, k / 2, -1};
@@ -243,7 +244,7 @@ int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float
     woff += (long)k * C * Cin;
   }
   b.chain = K;
-  return ft_launch_gemm_rows(&b, K, true, (hipStream_t)stream);
+  return ft_launch_gemm_rows(&b, K, !wp_transposed, (hipStream_t)stream);
 }
 
 static FtGemmTNTask conv_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T,

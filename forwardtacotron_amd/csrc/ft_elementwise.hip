@@ -14,6 +14,18 @@ __global__ void ft_pack_conv_w_kernel(const float* __restrict__ w, float* __rest
   wp[idx] = w[rem * k + j];
 }
 
+// tap-major TRANSPOSED pack for the data gradient: wpt[j][ci][co] = w[co][ci][j]  (K-contiguous in Cout, the
+// contraction index of dx = sum_j shift_j(dy) * W_j)
+__global__ void ft_pack_conv_wt_kernel(const float* __restrict__ w, float* __restrict__ wpt, int Cout, int Cin, int k) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Cout * Cin * k;
+  if (idx >= total) return;
+  int j = (int)(idx / ((long)Cout * Cin));
+  long rem = idx - (long)j * Cout * Cin;     // ci*Cout + co
+  int ci = (int)(rem / Cout), co = (int)(rem - (long)ci * Cout);
+  wpt[idx] = w[((long)co * Cin + ci) * k + j];
+}
+
 // ---- dropout (F.dropout, forward_tacotron.py:35 ; common_layers.py:106,110) -------------------------
 // Counter-based mask: keep(i) = hash(seed, i) >= p ; the backward re-derives the same mask from the seed,
 // so no mask tensor is stored.  out = keep ? x/(1-p) : 0
@@ -408,6 +420,15 @@ int ft_conv_pack_weight(const float* w, float* wp, int Cout, int Cin, int k, voi
   hipLaunchKernelGGL(ft_pack_conv_w_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wp, Cout,
                      Cin, k);
   return ft_check_launch("conv_pack_weight");
+}
+
+int ft_conv_pack_weight_t(const float* w, float* wpt, int Cout, int Cin, int k, void* stream) {
+  FT_REQUIRE(Cout >= 0 && Cin >= 0 && k >= 1, "conv_pack_weight_t: bad dims");
+  long total = (long)Cout * Cin * k;
+  if (total == 0) return FT_OK;
+  hipLaunchKernelGGL(ft_pack_conv_wt_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wpt,
+                     Cout, Cin, k);
+  return ft_check_launch("conv_pack_weight_t");
 }
 
 int ft_dropout(const float* x, float* out, long n, float p, uint64_t seed, void* stream) {

@@ -166,7 +166,7 @@ class ConvBiasFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            H.conv1d_bwd_data_raw(dy.data_ptr(), Cout, wp, dx, B, T, T, T, False)
+            H.conv1d_bwd_data_raw(dy.data_ptr(), Cout, wp, dx, B, T, T, T, False, w=w)
         dw = _emit(w, lambda o: H.conv1d_bwd_weight_raw(dy.data_ptr(), Cout, x, o, T, T), (dy, x))
         db = _emit(b, lambda o: H.colsum_raw(dy.data_ptr(), Cout, o, B * T, Cout), heavy=False)
         return dx, dw, db, None

@@ -107,6 +107,19 @@ def linear_multi_fwd(x: torch.Tensor, ws: List[torch.Tensor], biases: Optional[L
     return y
 
 
+# Data gradients contract over the OUTPUT features, which are the slow index of torch's [out,in] weights.  The
+# bf16-split MFMA kernel wants the contraction index contiguous in both operands, so the (small) weight is transposed
+# first and the product runs in the NT form; NT_GRADS = False keeps the [K][N] form on the f32 MFMA kernel.
+NT_GRADS = True
+
+
+def _wt(w: torch.Tensor):
+    """(pointer-holder tensor, flag) of the weight operand of a data gradient"""
+    if NT_GRADS and w.shape[0] % 4 == 0:
+        return transpose2d(w), 1
+    return w, 0
+
+
 def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, dx: Optional[torch.Tensor] = None, accumulate: bool = False,
                     dy_tm_B: int = 0, dx_tm_B: int = 0) -> torch.Tensor:
     """dx = dy @ w ; *_tm_B > 0: that side is time-major."""
@@ -121,16 +134,18 @@ def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, dx: Optional[torch.Tensor
         else:
             lead = tuple(dy.shape[:-1])
         dx = torch.empty(*lead, in_f, device=dy.device, dtype=dy.dtype)
-    _lib.call('ft_linear_bwd_data', _p(dy), out_f, _p(w), _p(dx), in_f, rows, in_f, out_f, int(accumulate),
-              dy_tm_B, dx_tm_B, _stream())
+    wt, flag = _wt(w)
+    _lib.call('ft_linear_bwd_data', _p(dy), out_f, _p(wt), _p(dx), in_f, rows, in_f, out_f, int(accumulate),
+              dy_tm_B, dx_tm_B, flag, _stream())
     return dx
 
 
 def linear_bwd_data_raw(dy_ptr: int, lddy: int, w: torch.Tensor, dx: torch.Tensor, rows: int, out_f: int,
                         accumulate: bool, dy_tm_B: int = 0, dx_tm_B: int = 0) -> None:
     in_f = w.shape[1]
-    _lib.call('ft_linear_bwd_data', dy_ptr, lddy, _p(w), _p(dx), in_f, rows, in_f, out_f, int(accumulate),
-              dy_tm_B, dx_tm_B, _stream())
+    wt, flag = _wt(w)
+    _lib.call('ft_linear_bwd_data', dy_ptr, lddy, _p(wt), _p(dx), in_f, rows, in_f, out_f, int(accumulate),
+              dy_tm_B, dx_tm_B, flag, _stream())
 
 
 def linear_bwd_data_multi(dy_ptrs: Sequence[int], lddy: int, ws: Sequence[torch.Tensor], dx: torch.Tensor, rows: int,
@@ -139,9 +154,11 @@ def linear_bwd_data_multi(dy_ptrs: Sequence[int], lddy: int, ws: Sequence[torch.
     n = len(ws)
     in_f = ws[0].shape[1]
     da = (ctypes.c_void_p * n)(*[int(p) for p in dy_ptrs])
-    wa = _ptr_array(ws)
+    flag = 1 if NT_GRADS and all(w.shape[0] % 4 == 0 for w in ws) else 0
+    wts = [transpose2d(w) for w in ws] if flag else list(ws)
+    wa = _ptr_array(wts)
     _lib.call('ft_linear_bwd_data_multi', n, ctypes.cast(da, c_void_p), lddy, ctypes.cast(wa, c_void_p), _p(dx), in_f,
-              rows, in_f, out_f, int(accumulate), dy_tm_B, dx_tm_B, _stream())
+              rows, in_f, out_f, int(accumulate), dy_tm_B, dx_tm_B, flag, _stream())
 
 
 def linear_bwd_weight_raw(dy_ptr: int, lddy: int, x_ptr: int, ldx: int, dw: torch.Tensor, rows: int, in_f: int,
@@ -213,19 +230,45 @@ def conv_bank_fwd(x: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, relu: b
 bank_probe = None
 
 
+def conv_pack_weight_t(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Cout,Cin,k] -> transposed tap-major [k,Cin,Cout] (weight operand of the data gradient in the NT form)"""
+    _chk(w, 'w')
+    Cout, Cin, k = w.shape
+    wpt = out if out is not None else torch.empty(k, Cin, Cout, device=w.device, dtype=w.dtype)
+    _lib.call('ft_conv_pack_weight_t', _p(w), _p(wpt), Cout, Cin, k, _stream())
+    return wpt
+
+
 def conv1d_bwd_data_raw(dy_ptr: int, lddy: int, wp: torch.Tensor, dx: torch.Tensor, B: int, T: int, Tbuf: int,
-                        Tvalid: int, accumulate: bool) -> None:
+                        Tvalid: int, accumulate: bool, w: Optional[torch.Tensor] = None) -> None:
+    """wp: packed [k,Cout,Cin]; with the original weight `w` at hand (and Cout % 4 == 0) the NT form is used"""
     k, Cout, Cin = wp.shape
+    if NT_GRADS and w is not None and Cout % 4 == 0:
+        wpt = conv_pack_weight_t(w)
+        _lib.call('ft_conv1d_bwd_data', dy_ptr, lddy, _p(wpt), _p(dx), Cin, B, T, Cin, Cout, k, Tbuf, Tvalid,
+                  int(accumulate), 1, _stream())
+        return
     _lib.call('ft_conv1d_bwd_data', dy_ptr, lddy, _p(wp), _p(dx), Cin, B, T, Cin, Cout, k, Tbuf, Tvalid,
-              int(accumulate), _stream())
+              int(accumulate), 0, _stream())
 
 
-def conv_bank_bwd_data(dy: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, Cin: int, T: int) -> torch.Tensor:
-    """dy [B,Tbuf,K*C] (gradient of the bank buffer) -> dx [B,T,Cin], all K members in one chained launch"""
+def conv_bank_bwd_data(dy: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, Cin: int, T: int,
+                       ws: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+    """dy [B,Tbuf,K*C] (gradient of the bank buffer) -> dx [B,T,Cin], all K members in one chained launch.
+    ws: the members' original [C,Cin,k] weights -> transposed packs, NT form."""
     _chk(dy, 'dy'); _chk(wp_all, 'wp_all')
     B, Tbuf, _ = dy.shape
     dx = torch.empty(B, T, Cin, device=dy.device, dtype=dy.dtype)
-    _lib.call('ft_conv_bank_bwd_data', _p(dy), K * C, _p(wp_all), _p(dx), Cin, B, T, Cin, C, K, Tbuf, _stream())
+    flag = 0
+    if NT_GRADS and ws is not None and C % 4 == 0:
+        wpt_all = torch.empty_like(wp_all)
+        off = 0
+        for i, w in enumerate(ws):
+            n = (i + 1) * C * Cin
+            conv_pack_weight_t(w, out=wpt_all[off:off + n].view(i + 1, Cin, C))
+            off += n
+        wp_all, flag = wpt_all, 1
+    _lib.call('ft_conv_bank_bwd_data', _p(dy), K * C, _p(wp_all), _p(dx), Cin, B, T, Cin, C, K, Tbuf, flag, _stream())
     return dx
 
 

@@ -206,7 +206,7 @@ class BatchNormConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            H.conv1d_bwd_data_raw(dy.data_ptr(), Cout, wp, dx, B, T, Tbuf, Tbuf, False)
+            H.conv1d_bwd_data_raw(dy.data_ptr(), Cout, wp, dx, B, T, Tbuf, Tbuf, False, w=w)
         dw = _emit(w, lambda out: H.conv1d_bwd_weight_raw(dy.data_ptr(), Cout, x, out, Tbuf, Tbuf), (dy, x))
         dres = dout if ctx.has_res else None
         return dx, dw, dgamma, dbeta, dres, None, None, None
@@ -246,7 +246,7 @@ class ConvBankFn(Function):
         B, T, Cin = x.shape
         dz = H.maxpool2_bwd(_c(dout), z)
         dy, dgamma, dbeta = H.bn_bwd(dz, ybank, gamma, mean, rstd, group=C, relu=True)
-        dx = H.conv_bank_bwd_data(dy, wp_all, K, C, Cin, T) if ctx.needs_input_grad[0] else None
+        dx = H.conv_bank_bwd_data(dy, wp_all, K, C, Cin, T, ws=ws) if ctx.needs_input_grad[0] else None
         dws = []
         off = 0
         for i in range(K):

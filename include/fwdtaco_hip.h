@@ -43,9 +43,10 @@ int ft_linear_fwd(const float* x, long ldx, const float* w, const float* bias, f
 int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
                         float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
                         int x_tm_B, int y_tm_B, void* stream);
-/* dx[rows,in_f] (+)= dy[rows,out_f] * w[out_f,in_f] */
+/* dx[rows,in_f] (+)= dy[rows,out_f] * w[out_f,in_f] ; w_transposed = 1: `w` points at w^T [in_f,out_f] instead
+ * (both operands then have the contraction index contiguous -- the form the bf16-split MFMA kernel takes) */
 int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, long lddx, int rows, int in_f,
-                       int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream);
+                       int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed, void* stream);
 /* dw[out_f,in_f] (+)= dy^T * shift(x): rows = B*T logical positions; x_shift != 0 reads x row (b, t+x_shift),
  * zero outside [0,T) (recurrent-weight gradients: h_{t-1} / h_{t+1}); dy_time_major / x_time_major = 1 when
  * that operand is stored [T,B,*].  Deterministic split + ordered reduce. */
@@ -60,6 +61,9 @@ int ft_linear_bwd_weight(const float* dy, long lddy, const float* x, long ldx, f
  * t' in [0,Tout); Tout = T (odd k, or even k sliced as the CBHG does, common_layers.py:99) or T+1 (even k);
  * accumulate=1 adds the result onto y (residual connection, common_layers.py:114). */
 int ft_conv_pack_weight(const float* w, float* wp, int Cout, int Cin, int k, void* stream);
+/* transposed tap-major pack wpt[k][Cin][Cout] for the data gradients (`wp_transposed` = 1 below): the contraction
+ * index Cout becomes contiguous, which lets the gradient GEMM run in the NT form (see `w_transposed`) */
+int ft_conv_pack_weight_t(const float* w, float* wpt, int Cout, int Cin, int k, void* stream);
 int ft_conv1d_fwd(const float* x, long ldx, const float* wp, const float* scale, const float* shift, float* y,
                   long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, int accumulate,
                   void* stream);
@@ -69,16 +73,17 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
                      float* ybank, int B, int T, int Cin, int C, int K, int Tout, int relu, void* stream);
 /* dx[b,t,ci] (+)= sum_j sum_co dy[b, t-j+k/2, co] * w[co,ci,j]; dy is [B,Tbuf,*] of which rows < Tvalid count */
 int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
-                       int Cout, int k, int Tbuf, int Tvalid, int accumulate, void* stream);
+                       int Cout, int k, int Tbuf, int Tvalid, int accumulate, int wp_transposed, void* stream);
 /* dx (+)= sum_i dy_i[rows,out_f] * w_i[out_f,in_f]: the data gradients of several nn.Linear that read the same input
  * (HighwayNetwork W1/W2, common_layers.py:35-40; the two directions' W_ih of nn.GRU / nn.LSTM) in ONE launch,
  * accumulated in registers.  dy / w: host arrays of ntasks device pointers (ntasks <= 16). */
 int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
-                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, void* stream);
+                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
+                             void* stream);
 /* data gradient of the whole conv bank (backward of common_layers.py:97-102) in ONE launch: the K members' products
  * are accumulated in registers into dx[B,T,Cin]; dy = [B,Tbuf,K*C] gradient of the bank buffer (Tbuf = T or T+1) */
 int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
-                          int C, int K, int Tbuf, void* stream);
+                          int C, int K, int Tbuf, int wp_transposed, void* stream);
 /* dw[co,ci,j] = sum_{b,t'<Tvalid} dy[b,t',co] * x[b,t'+j-k/2,ci]   (torch layout [Cout][Cin][k]) */
 size_t ft_conv1d_bwd_weight_workspace(int B, int T, int Cin, int Cout, int k, int Tvalid);
 int ft_conv1d_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T, int Cin,
