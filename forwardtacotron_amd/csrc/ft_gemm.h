@@ -70,6 +70,8 @@ struct FtGemmTNTask {
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream);
 // fp32 on the bf16 matrix pipe (exact 3-way operand split, ft_gemm_b3.hip); NT + FAST launches, FT_GEMM_B3=0 disables
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream);
+int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
+                         hipStream_t stream);
 bool ft_gemm_b3_enabled();
 int ft_launch_gemm_tn(const FtGemmTNTask& task, float* workspace, size_t workspace_floats,
                       hipStream_t stream);

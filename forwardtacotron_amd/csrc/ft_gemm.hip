@@ -638,7 +638,10 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
   GemmLog log;
   log.begin(stream);
-  if (p.tm == 2) {
+  const bool b3 = fast && ft_gemm_b3_enabled();
+  if (b3) {
+    (void)ft_launch_gemm_tn_b3(t, workspace, p.S, p.rows_per_split, p.tm, grid, stream);
+  } else if (p.tm == 2) {
     if (fast) hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2, true>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
     else hipLaunchKernelGGL((ft_gemm_tn_kernel<2, 2, false>), grid, dim3(256), 0, stream, t, workspace, p.S, p.rows_per_split);
   } else {

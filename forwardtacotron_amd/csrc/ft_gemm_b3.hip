@@ -237,7 +237,213 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// TN (weight gradients): slab[z][m][n] = sum_{r in slice} A[map_a(r)][m] * B[map_b,tap(r)][n].  The contraction index
+// is the ROW index of both operands, so the staging transposes on the fly: a thread fetches a 4(r) x 4(m) block as
+// four 16-B loads (coalesced along m), regroups it in registers into four 4(r)-vectors, splits them and writes three
+// 8-B pieces per output row -- the LDS tiles come out [m][plane][32 r], the same fragment layout as the rows kernel.
+template <int TM, int TN>
+__global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, float* slab, int S, int rows_per_split) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int MQ = BM / 4, NQ = BN / 4;            // column quads per tile
+  constexpr int ABLK = MQ * 8, BBLK = NQ * 8;        // 4x4 blocks per stage (8 row quads of 4)
+  constexpr int PA = (ABLK + BBLK <= 256) ? 1 : ABLK / 256;     // blocks per thread
+  constexpr int PB = (ABLK + BBLK <= 256) ? 1 : BBLK / 256;
+  constexpr bool SHARED = ABLK + BBLK <= 256;        // 64x64 tile: threads 0..127 stage A, 128..255 stage B
+  __shared__ __attribute__((aligned(16))) unsigned short smem[(BM + BN) * RS];
+  unsigned short* As = smem;
+  unsigned short* Bs = smem + BM * RS;
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int zts = blockIdx.z / S, s = blockIdx.z - zts * S;
+  const int zi = zts / T.taps, tap = zts - zi * T.taps;
+  const float* TA = T.A;
+  const float* TB = T.B;
+  if (T.nz > 1) {
+    const int z0 = zi / T.nz1, z1 = zi - z0 * T.nz1;
+    TA += z0 * T.sA0 + z1 * T.sA1;
+    TB += z0 * T.sB0 + z1 * T.sB1;
+  }
+  const int r_begin = s * rows_per_split;
+  const int r_end = min(T.R, r_begin + rows_per_split);
+  const int tid = threadIdx.x;
+  const int tM = T.M, tN = T.N;
+  const long lda = T.lda, ldb = T.ldb;
+  const int aTlog = T.amap.Tlog, aTvalid = T.amap.Tvalid, bTlog = T.bmap.Tlog, bTvalid = T.bmap.Tvalid;
+  const long abst = T.amap.bstride, atst = T.amap.tstride, bbst = T.bmap.bstride, btst = T.bmap.tstride;
+  const int ashift = T.amap.shift0 + tap * T.amap.shift_step;
+  const int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
+
+  // staging role of this thread: which operand, which column quad, which row quad
+  const bool doA = SHARED ? tid < ABLK : true;
+  const bool doB = SHARED ? tid >= ABLK : true;
+  const int ta = SHARED ? tid : tid;                 // block index within A (p-th block: ta + 256 p)
+  const int tb = SHARED ? tid - ABLK : tid;
+  // (item, t) of the first of the 4 rows of every block, tracked incrementally (stages come in order, 32 rows apart)
+  int a_b[PA][4], a_t[PA][4], b_b[PB][4], b_t[PB][4];
+#pragma unroll
+  for (int p = 0; p < PA; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r_begin + 4 * ((ta + 256 * p) / MQ) + i;
+      a_b[p][i] = r / aTlog;
+      a_t[p][i] = r - a_b[p][i] * aTlog;
+    }
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r_begin + 4 * ((tb + 256 * p) / NQ) + i;
+      b_b[p][i] = r / bTlog;
+      b_t[p][i] = r - b_b[p][i] * bTlog;
+    }
+  int r_next = r_begin;
+
+  float4 ra[PA][4], rb[PB][4];
+  auto load_stage = [&]() {
+    if (doA) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const int blk = ta + 256 * p, mq = blk % MQ, rq = blk / MQ;
+        const int am = m0 + 4 * mq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = r_next + 4 * rq + i;
+          const int ts = a_t[p][i] + ashift;
+          const bool ok = (r < r_end) & (ts >= 0) & (ts < aTvalid) & (am < tM);
+          ra[p][i] = ld4_sel(TA + ((long)a_b[p][i] * abst + (long)ts * atst) * lda + am, TA, ok);
+          a_t[p][i] += BK;
+          while (a_t[p][i] >= aTlog) {
+            a_t[p][i] -= aTlog;
+            ++a_b[p][i];
+          }
+        }
+      }
+    }
+    if (doB) {
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        const int blk = tb + 256 * p, nq = blk % NQ, rq = blk / NQ;
+        const int bn = n0 + 4 * nq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = r_next + 4 * rq + i;
+          const int ts = b_t[p][i] + bshift;
+          const bool ok = (r < r_end) & (ts >= 0) & (ts < bTvalid) & (bn < tN);
+          rb[p][i] = ld4_sel(TB + ((long)b_b[p][i] * bbst + (long)ts * btst) * ldb + bn, TB, ok);
+          b_t[p][i] += BK;
+          while (b_t[p][i] >= bTlog) {
+            b_t[p][i] -= bTlog;
+            ++b_b[p][i];
+          }
+        }
+      }
+    }
+    r_next += BK;
+  };
+  auto store_stage = [&]() {
+    if (doA) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const int blk = ta + 256 * p, mq = blk % MQ, rq = blk / MQ;
+        unsigned short* base = As + (4 * mq) * RS + 4 * rq;
+        store_split(base + 0 * RS, make_float4(ra[p][0].x, ra[p][1].x, ra[p][2].x, ra[p][3].x));
+        store_split(base + 1 * RS, make_float4(ra[p][0].y, ra[p][1].y, ra[p][2].y, ra[p][3].y));
+        store_split(base + 2 * RS, make_float4(ra[p][0].z, ra[p][1].z, ra[p][2].z, ra[p][3].z));
+        store_split(base + 3 * RS, make_float4(ra[p][0].w, ra[p][1].w, ra[p][2].w, ra[p][3].w));
+      }
+    }
+    if (doB) {
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        const int blk = tb + 256 * p, nq = blk % NQ, rq = blk / NQ;
+        unsigned short* base = Bs + (4 * nq) * RS + 4 * rq;
+        store_split(base + 0 * RS, make_float4(rb[p][0].x, rb[p][1].x, rb[p][2].x, rb[p][3].x));
+        store_split(base + 1 * RS, make_float4(rb[p][0].y, rb[p][1].y, rb[p][2].y, rb[p][3].y));
+        store_split(base + 2 * RS, make_float4(rb[p][0].z, rb[p][1].z, rb[p][2].z, rb[p][3].z));
+        store_split(base + 3 * RS, make_float4(rb[p][0].w, rb[p][1].w, rb[p][2].w, rb[p][3].w));
+      }
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (r_begin < r_end) {
+    const unsigned short* ap = As + (wm * 32 * TM + l31) * RS + 8 * half;
+    const unsigned short* bp = Bs + (wn * 32 * TN + l31) * RS + 8 * half;
+    const int nch = (r_end - r_begin + BK - 1) / BK;
+    load_stage();
+    store_stage();
+    if (nch > 1) load_stage();
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            a[i][pl] = *reinterpret_cast<const bf16x8*>(ap + 32 * i * RS + 32 * pl + 16 * ks);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            b[j][pl] = *reinterpret_cast<const bf16x8*>(bp + 32 * j * RS + 32 * pl + 16 * ks);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+      if (c + 1 < nch) {
+        store_stage();
+        if (c + 2 < nch) load_stage();
+        __syncthreads();
+      }
+    }
+  }
+  float* out = slab + (long)blockIdx.z * tM * tN;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + l31;
+      if (col >= tN) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row < tM) out[(long)row * tN + col] = acc[i][j][e];
+      }
+    }
+}
+
 }  // namespace
+
+int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
+                         hipStream_t stream) {
+  if (tm == 2)
+    hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<2, 2>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+  else
+    hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<1, 1>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+  return FT_OK;
+}
 
 // NT, FAST (16-B aligned operands, K % 4 == 0) launches only; grid / tile choice made by ft_launch_gemm_rows
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream) {
