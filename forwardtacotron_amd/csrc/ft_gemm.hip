@@ -591,7 +591,8 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   } while (0)
   GemmLog log;
   log.begin(stream);
-  const bool b3 = fast && !b_ncontig && ft_gemm_b3_enabled();
+  // the 64x64 tile gains nothing from the split path (its staging per MFMA is twice the 128-tile's): f32 kernel there
+  const bool b3 = fast && !b_ncontig && big && ft_gemm_b3_enabled();
   if (b3) {
     (void)ft_launch_gemm_rows_b3(*batch, big, grid, stream);
   } else if (big) {
@@ -638,7 +639,13 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
   GemmLog log;
   log.begin(stream);
-  const bool b3 = fast && ft_gemm_b3_enabled();
+  // measured (profiles/r01c_gemm_report_f32.txt vs r01c_gemm_report_b3_all.txt): the transposing staging of the bf16-split TN form costs what its MFMAs
+  // save (128-tiles: 104 vs 104 TF) and loses on the 64-tiles (43 vs 62 TF), so it stays opt-in (FT_GEMM_B3_TN=1)
+  static const bool b3_tn = [] {
+    const char* e = getenv("FT_GEMM_B3_TN");
+    return e && e[0] == '1';
+  }();
+  const bool b3 = fast && b3_tn && ft_gemm_b3_enabled();
   if (b3) {
     (void)ft_launch_gemm_tn_b3(t, workspace, p.S, p.rows_per_split, p.tm, grid, stream);
   } else if (p.tm == 2) {
