@@ -41,6 +41,34 @@ def test_linear_fwd_bwd(H, rows, in_f, out_f):
     assert rel_err(dw, dy.double().t() @ x.double()) < 2e-6
 
 
+def test_large_gemm_split_path_is_fp32_accurate(H):
+    """Shapes big enough for the 128x128 tile, i.e. the bf16-split MFMA kernel (6 bf16 products per fp32 product of an
+    exact 3-way operand split): full-mantissa operands over a wide dynamic range, checked against float64 to the
+    same relative bar as the f32-MFMA path, forward, data gradient (NT form through the transposed weight) and a
+    5-tap convolution with row shifts."""
+    g = torch.Generator().manual_seed(77)
+    rows, in_f, out_f = 8192, 512, 768
+    x = torch.randn(rows, in_f, generator=g) * torch.exp(3 * torch.randn(rows, 1, generator=g))      # rows span ~e^±9
+    w = torch.randn(out_f, in_f, generator=g) * torch.exp(torch.randn(out_f, 1, generator=g))
+    b = torch.randn(out_f, generator=g)
+    y = H.linear_fwd(dev(x), dev(w), dev(b))
+    ref = x.double() @ w.double().t() + b.double()
+    row_scale = (x.double().abs() @ w.double().abs().t()) + b.double().abs()     # sum |a||b| + |bias|: the error scale
+    # f32-class arithmetic lands at ~2e-7 here; a 2-way (hi+lo) split would sit near 3e-6
+    assert float(((y.cpu().double() - ref).abs() / row_scale).max()) < 1e-6
+    dy = torch.randn(rows, out_f, generator=g)
+    dx = H.linear_bwd_data(dev(dy), dev(w))
+    refd = dy.double() @ w.double()
+    scale_d = dy.double().abs() @ w.double().abs() + 1e-30
+    assert float(((dx.cpu().double() - refd).abs() / scale_d).max()) < 1e-6
+    B, T, Cin, Cout, k = 32, 600, 128, 256, 5
+    xc = torch.randn(B, T, Cin, generator=g)
+    wc = torch.randn(Cout, Cin, k, generator=g)
+    yc = H.conv1d_fwd(dev(xc), H.conv_pack_weight(dev(wc)), relu=False)
+    refc = _conv_ref(xc, wc, False)[:, :T]
+    assert rel_err(yc, refc) < 2e-6
+
+
 def test_linear_multi(H):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(3, 50, 24, generator=g)
