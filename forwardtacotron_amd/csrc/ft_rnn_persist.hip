@@ -37,6 +37,40 @@ constexpr unsigned MAX_SPINS = 1u << 18;
 constexpr int MB = 16;                 // batch rows per workgroup
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+// exact 3-way bf16 split of 8 fp32 values (x = hi + mid + lo, truncation splits; see ft_gemm_b3.hip): the recurrent
+// matmuls then run as six v_mfma_f32_16x16x32_bf16 per 32-k block instead of eight v_mfma_f32_16x16x4_f32 --
+// 2.67x fewer matrix-pipe cycles at fp32-class accuracy (B3 variants of the kernels below; need H % 32 == 0)
+__device__ __forceinline__ void split8(const float4& v0, const float4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  u16x8 h, m, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned hb = __float_as_uint(f[i]) & 0xFFFF0000u;
+    const float r1 = f[i] - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    h[i] = (unsigned short)(hb >> 16);
+    m[i] = (unsigned short)(mb >> 16);
+    l[i] = (unsigned short)(__float_as_uint(r2) >> 16);
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  mid = __builtin_bit_cast(bf16x8, m);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+__device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);      // small terms first
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+__device__ __forceinline__ float4 as_f4(const u32x4& v) {
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 struct Geom {
   int nchunks, nbg, total;             // chunks per group, batch groups, workgroups that have work
@@ -82,10 +116,10 @@ __device__ __forceinline__ bool decode(const Geom& g, int& d, int& bgp, int& chu
 // ---------------------------------------------------------------------------------------------------
 // forward: workgroup = 16 batch rows x 8 hidden units (all G gates = 2 column tiles), K = H over NW waves
 // ---------------------------------------------------------------------------------------------------
-template <int G, int NW>
+template <int G, int NW, bool B3>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                      unsigned* err, unsigned xb_bytes) {
-  constexpr int UB = 8, NT = 2;
+  constexpr int UB = 8, NT = 2, BCH = GCH / 2;
   __shared__ float red[NW * NT * 16 * RLD];
   __shared__ int s_ok;
   int d, bgp, chunk, grp;
@@ -107,16 +141,32 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
   const int ngroups = H / 16;
   const int gpw = (ngroups + NW - 1) / NW;
   const int g0 = wave * gpw, g1 = min(ngroups, g0 + gpw);
-  float4 bv[NT][GCH];
+  // B3: 32-k blocks [kb0, kb1) of this wave, W fragments pre-split into (hi, mid, lo) once
+  const int nblk = H / 32;
+  const int bpw = (nblk + NW - 1) / NW;
+  const int kb0 = wave * bpw, kb1 = min(nblk, kb0 + bpw);
+  float4 bv[NT][B3 ? 1 : GCH];
+  bf16x8 bw[NT][B3 ? BCH : 1][3];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = nt * 16 + l15, gj = col / UB, ul = col - gj * UB;
     const bool valid = gj < G;
     const float* brow = a.whh[d] + (valid ? ((long)gj * H + u0 + ul) * H : 0);
+    if constexpr (!B3) {
 #pragma unroll
-    for (int c = 0; c < GCH; ++c)
-      bv[nt][c] = (valid && g0 + c < g1) ? *reinterpret_cast<const float4*>(brow + 16 * (g0 + c) + 4 * q)
-                                         : make_float4(0, 0, 0, 0);
+      for (int c = 0; c < GCH; ++c)
+        bv[nt][c] = (valid && g0 + c < g1) ? *reinterpret_cast<const float4*>(brow + 16 * (g0 + c) + 4 * q)
+                                           : make_float4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int c = 0; c < BCH; ++c) {
+        const bool in = valid && kb0 + c < kb1;
+        const float* p = brow + (in ? 32 * (kb0 + c) + 8 * q : 0);
+        const float4 z = make_float4(0, 0, 0, 0);
+        split8(in ? *reinterpret_cast<const float4*>(p) : z, in ? *reinterpret_cast<const float4*>(p + 4) : z,
+               bw[nt][c][0], bw[nt][c][1], bw[nt][c][2]);
+      }
+    }
   }
 
   // ---- cell threads (waves 0 and 1): wave jq owns units 4*jq..4*jq+3 of the chunk = one [16][4] exchange block
@@ -148,7 +198,8 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[nt][e] = 0.f;
-    float4 av[GCH];
+    float4 av[B3 ? 1 : GCH];
+    float4 aw[B3 ? BCH : 1][2];
     if (s > 0) {
       if (wave == 0) {
         const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
@@ -160,12 +211,22 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
         return;
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
+      if constexpr (!B3) {
 #pragma unroll
-      for (int c = 0; c < GCH; ++c)
-        if (g0 + c < g1) {
-          const long quad = 4 * (g0 + c) + q;
-          av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
-        }
+        for (int c = 0; c < GCH; ++c)
+          if (g0 + c < g1) {
+            const long quad = 4 * (g0 + c) + q;
+            av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < BCH; ++c)
+          if (kb0 + c < kb1) {                      // lane (row l15, q): k = 32 blk + 8 q .. +7 = two exchange quads
+            const long quad = 8 * (kb0 + c) + 2 * q;
+            aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+            aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
+          }
+      }
     }
     // next step's x projection, requested behind the exchange loads
     float xn[G];
@@ -178,12 +239,23 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
     }
     if (s > 0) {
+      if constexpr (!B3) {
 #pragma unroll
-      for (int c = 0; c < GCH; ++c)
-        if (g0 + c < g1) {
+        for (int c = 0; c < GCH; ++c)
+          if (g0 + c < g1) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) mfma4(av[c], bv[nt][c], acc[nt]);
-        }
+            for (int nt = 0; nt < NT; ++nt) mfma4(av[c], bv[nt][c], acc[nt]);
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < BCH; ++c)
+          if (kb0 + c < kb1) {
+            bf16x8 a3[3];
+            split8(aw[c][0], aw[c][1], a3[0], a3[1], a3[2]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mfma6(a3, bw[nt][c], acc[nt]);
+          }
+      }
     }
     store_partials<NT>(red, wave, lane, acc);
     __syncthreads();
@@ -250,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
 // ---------------------------------------------------------------------------------------------------
 // backward: workgroup = 16 batch rows x 16 hidden units, K = G*H over NW waves
 // ---------------------------------------------------------------------------------------------------
-template <int G, int NW, int GW>
+template <int G, int NW, int GW, bool B3>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                      unsigned* err, unsigned xb_bytes) {
   __shared__ float red[NW * 16 * RLD];
@@ -275,10 +347,26 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
   const int ngroups = K / 16;
   const int gpw = (ngroups + NW - 1) / NW;
   const int g0 = wave * gpw, g1 = min(ngroups, g0 + gpw);
-  float4 bv[GW];
+  constexpr int BW = GW / 2;                        // B3: 32-k blocks per wave
+  const int nblk = K / 32;
+  const int bpw = (nblk + NW - 1) / NW;
+  const int kb0 = wave * bpw, kb1 = min(nblk, kb0 + bpw);
+  float4 bv[B3 ? 1 : GW];
+  bf16x8 bw[B3 ? BW : 1][3];
+  if constexpr (!B3) {
 #pragma unroll
-  for (int c = 0; c < GW; ++c)
-    bv[c] = (g0 + c < g1) ? *reinterpret_cast<const float4*>(brow + 16 * (g0 + c) + 4 * q) : make_float4(0, 0, 0, 0);
+    for (int c = 0; c < GW; ++c)
+      bv[c] = (g0 + c < g1) ? *reinterpret_cast<const float4*>(brow + 16 * (g0 + c) + 4 * q) : make_float4(0, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int c = 0; c < BW; ++c) {
+      const bool in = kb0 + c < kb1;
+      const float* p = brow + (in ? 32 * (kb0 + c) + 8 * q : 0);
+      const float4 z = make_float4(0, 0, 0, 0);
+      split8(in ? *reinterpret_cast<const float4*>(p) : z, in ? *reinterpret_cast<const float4*>(p + 4) : z, bw[c][0],
+             bw[c][1], bw[c][2]);
+    }
+  }
 
   // ---- cell threads (first 256): wave j4 owns units 4*j4..4*j4+3 -> whole [16][4] exchange blocks, one per gate
   const int j4 = tid >> 6, ci = (tid >> 2) & 15, jj = tid & 3;
@@ -321,7 +409,8 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
     f32x4 acc[1];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] = 0.f;
-    float4 av[GW];
+    float4 av[B3 ? 1 : GW];
+    float4 aw[B3 ? BW : 1][2];
     if (s > 0) {
       if (wave == 0) {
         const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
@@ -333,19 +422,39 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
         return;
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
+      if constexpr (!B3) {
 #pragma unroll
-      for (int c = 0; c < GW; ++c)
-        if (g0 + c < g1) {
-          const long quad = 4 * (g0 + c) + q;
-          av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
-        }
+        for (int c = 0; c < GW; ++c)
+          if (g0 + c < g1) {
+            const long quad = 4 * (g0 + c) + q;
+            av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < BW; ++c)
+          if (kb0 + c < kb1) {
+            const long quad = 8 * (kb0 + c) + 2 * q;
+            aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+            aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
+          }
+      }
     }
     float ngv[4], ndo, ncc, nprev;
     request(s + 1, ngv, ndo, ncc, nprev);
     if (s > 0) {
+      if constexpr (!B3) {
 #pragma unroll
-      for (int c = 0; c < GW; ++c)
-        if (g0 + c < g1) mfma4(av[c], bv[c], acc[0]);
+        for (int c = 0; c < GW; ++c)
+          if (g0 + c < g1) mfma4(av[c], bv[c], acc[0]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < BW; ++c)
+          if (kb0 + c < kb1) {
+            bf16x8 a3[3];
+            split8(aw[c][0], aw[c][1], a3[0], a3[1], a3[2]);
+            mfma6(a3, bw[c], acc[0]);
+          }
+      }
     }
     store_partials<1>(red, wave, lane, acc);
     __syncthreads();
@@ -467,11 +576,11 @@ bool grid_fits(KernelT kernel, int block, long nblocks) {
   return per_cu >= 1 && nblocks <= (long)per_cu * device_cus();
 }
 
-template <int G, int NW>
+template <int G, int NW, bool B3>
 int launch_fwd_persist(const RnnFwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  if (!grid_fits(ft_rnn_fwd_persist_kernel<G, NW>, NW * 64, grid)) return -1;
+  if (!grid_fits(ft_rnn_fwd_persist_kernel<G, NW, B3>, NW * 64, grid)) return -1;
   (void)hipMemsetAsync(p.err, 0, p.total_bytes, stream);
-  hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
+  hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
                      p.err, (unsigned)p.xb_bytes);
   return ft_check_launch("rnn_fwd_persistent");
 }
@@ -494,14 +603,18 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   const int grid = 8 * ft_cdiv(geo.total, 8);
   a.s = 0;
-  return NW == 8 ? launch_fwd_persist<G, 8>(a, geo, p, grid, stream) : launch_fwd_persist<G, 4>(a, geo, p, grid, stream);
+  if (H % 32 == 0 && ft_cdiv(H / 32, NW) <= GCH / 2 && env_int("FT_RNN_B3", 1))     // matmul on the bf16 pipe (exact split)
+    return NW == 8 ? launch_fwd_persist<G, 8, true>(a, geo, p, grid, stream)
+                   : launch_fwd_persist<G, 4, true>(a, geo, p, grid, stream);
+  return NW == 8 ? launch_fwd_persist<G, 8, false>(a, geo, p, grid, stream)
+                 : launch_fwd_persist<G, 4, false>(a, geo, p, grid, stream);
 }
 
-template <int G, int NW, int GW>
+template <int G, int NW, int GW, bool B3>
 int launch_bwd_persist(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  if (!grid_fits(ft_rnn_bwd_persist_kernel<G, NW, GW>, NW * 64, grid)) return -1;
+  if (!grid_fits(ft_rnn_bwd_persist_kernel<G, NW, GW, B3>, NW * 64, grid)) return -1;
   (void)hipMemsetAsync(p.err, 0, p.total_bytes, stream);
-  hipLaunchKernelGGL((ft_rnn_bwd_persist_kernel<G, NW, GW>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
+  hipLaunchKernelGGL((ft_rnn_bwd_persist_kernel<G, NW, GW, B3>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
                      p.err, (unsigned)p.xb_bytes);
   return ft_check_launch("rnn_bwd_persistent");
 }
@@ -527,10 +640,16 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   const int grid = 8 * ft_cdiv(geo.total, 8);
   a.s = 0;
-  if (NW == 16) return launch_bwd_persist<G, 16, 16>(a, geo, p, grid, stream);
-  if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16>(a, geo, p, grid, stream)
-                               : launch_bwd_persist<G, 8, 8>(a, geo, p, grid, stream);
-  return launch_bwd_persist<G, 4, 8>(a, geo, p, grid, stream);
+  if (K % 32 == 0 && ft_cdiv(K / 32, NW) <= GW / 2 && env_int("FT_RNN_B3", 1)) {
+    if (NW == 16) return launch_bwd_persist<G, 16, 16, true>(a, geo, p, grid, stream);
+    if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, true>(a, geo, p, grid, stream)
+                                 : launch_bwd_persist<G, 8, 8, true>(a, geo, p, grid, stream);
+    return launch_bwd_persist<G, 4, 8, true>(a, geo, p, grid, stream);
+  }
+  if (NW == 16) return launch_bwd_persist<G, 16, 16, false>(a, geo, p, grid, stream);
+  if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, false>(a, geo, p, grid, stream)
+                               : launch_bwd_persist<G, 8, 8, false>(a, geo, p, grid, stream);
+  return launch_bwd_persist<G, 4, 8, false>(a, geo, p, grid, stream);
 }
 
 }  // namespace
