@@ -10,8 +10,11 @@
 // Tiling: 256 threads = 4 wave64 in 2x2, each wave TMxTN tiles of 32x32 (f32 accumulators in
 // AGPR/VGPR), BK = 32 per stage.  LDS tiles are K-major ([k][m]) so the MFMA operand fetch
 // (lane l: row l&31, k = kk + (l>>5)) is a conflict-free ds_read_b32 across 32 consecutive floats.
-// f32 MFMA runs at 64 cycles / instruction / SIMD, so operand staging (register prefetch of the next
-// K-stage while the current one is multiplied) is far from the bottleneck; the kernel is MFMA-bound.
+// Measured ceiling of this tiling as a plain GEMM: 105-113 TFLOP/s of the 157 the f32 MFMA pipe offers
+// (scratch/gemm_lab.hip: operands in registers only 133-143, + LDS fetch 127-134, + LDS stores 120-130, + global
+// loads 105-113); these kernels reach 87-102 with row maps, taps and fused epilogues.  The 128x128 NT launches are
+// routed to the bf16-split kernel of ft_gemm_b3.hip instead (136-148 TFLOP/s fp32-equivalent); this file keeps the
+// 64x64 tiles, the [K][N] operand form, unaligned / odd shapes and the TN (weight-gradient) kernel.
 #include "ft_gemm.h"
 
 namespace {

@@ -2,8 +2,12 @@
 // (models/common_layers.py:89,123 ; models/forward_tacotron.py:24,96-99,147-152).
 //
 // The input projections x*W_ih^T (+b_ih) are hoisted into one big MFMA GEMM (ft_linear_multi_fwd); what is
-// left per timestep is h[B,H] * W_hh^T[H,G*H] plus the cell math.  The recurrence issues ONE launch per
-// timestep covering both directions; the kernel boundary is the step-to-step dependency.
+// left per timestep is h[B,H] * W_hh^T[H,G*H] plus the cell math.
+//
+// This file: the C entry points and the PER-STEP form (one launch per timestep covering both directions; the kernel
+// boundary is the step-to-step dependency).  It is the fallback -- hidden sizes that are not a multiple of 16, a grid
+// that would not be co-resident, FT_RNN_PERSISTENT=0; the normal path is the one-launch persistent form in
+// ft_rnn_persist.hip (ft_rnn_{fwd,bwd}_persistent), tried first by rnn_fwd / rnn_bwd below.
 //
 // Per step the chip has to move W_hh (4 MB per direction for the 512-wide LSTM) plus the recurrent operand
 // through the per-CU L1 path, so the decomposition minimises BYTES PER CU rather than MFMA count:
