@@ -68,45 +68,55 @@ class ConditionalSeriesPredictor(nn.Module):
 class MultiFastPitch(nn.Module):
     """Drop-in for models/multi_fast_pitch.py:93-328."""
 
-    def __init__(self, num_chars: int,
-                 durpred_dropout: float, durpred_d_model: int, durpred_n_heads: int, durpred_layers: int,
-                 durpred_d_fft: int,
-                 pitch_dropout: float, pitch_d_model: int, pitch_n_heads: int, pitch_layers: int, pitch_d_fft: int,
-                 energy_dropout: float, energy_d_model: int, energy_n_heads: int, energy_layers: int,
-                 energy_d_fft: int,
-                 pitch_cond_d_model: int, pitch_cond_n_heads: int, pitch_cond_layers: int, pitch_cond_d_fft: int,
-                 pitch_cond_dropout: float, pitch_cond_output_dims: int,
-                 pitch_strength: float, energy_strength: float, d_model: int, conv1_kernel: int, conv2_kernel: int,
-                 prenet_layers: int, prenet_heads: int, prenet_fft: int, prenet_dropout: float,
-                 postnet_layers: int, postnet_heads: int, postnet_fft: int, postnet_dropout: float,
-                 n_mels: int, speaker_emb_dims: int, padding_value=PAD_VALUE):
+    # Constructor keywords = the keys of config['multi_fast_pitch']['model'] (+ num_chars, n_mels), exactly the
+    # reference's (multi_fast_pitch.py:95-133).  Four predictors share one hyper-parameter pattern
+    # `<prefix>_{d_model,n_heads,layers,d_fft,dropout}`, the two transformers `<prefix>_{layers,heads,fft,dropout}`.
+    _PREDICTORS = ('durpred', 'pitch', 'energy', 'pitch_cond')
+    _TRUNKS = ('prenet', 'postnet')
+    _SCALARS = ('num_chars', 'n_mels', 'speaker_emb_dims', 'd_model', 'conv1_kernel', 'conv2_kernel',
+                'pitch_strength', 'energy_strength', 'pitch_cond_output_dims')
+
+    @classmethod
+    def _expected(cls):
+        keys = list(cls._SCALARS)
+        keys += [f'{p}_{k}' for p in cls._PREDICTORS for k in ('d_model', 'n_heads', 'layers', 'd_fft', 'dropout')]
+        keys += [f'{p}_{k}' for p in cls._TRUNKS for k in ('layers', 'heads', 'fft', 'dropout')]
+        return keys
+
+    def __init__(self, padding_value=PAD_VALUE, **hp):
         super().__init__()
+        want = self._expected()
+        missing = [k for k in want if k not in hp]
+        extra = [k for k in hp if k not in want]
+        if missing or extra:
+            raise TypeError(f'MultiFastPitch(): missing {missing}, unexpected {extra}')
         self.padding_value = padding_value
         self.lr = LengthRegulator()
-        common = dict(num_chars=num_chars, conv1_kernel=conv1_kernel, conv2_kernel=conv2_kernel,
-                      speaker_emb_dims=speaker_emb_dims)
-        self.dur_pred = ConditionalSeriesPredictor(d_model=durpred_d_model, n_heads=durpred_n_heads,
-                                                   layers=durpred_layers, d_fft=durpred_d_fft,
-                                                   dropout=durpred_dropout, **common)
-        self.pitch_pred = ConditionalSeriesPredictor(d_model=pitch_d_model, n_heads=pitch_n_heads, layers=pitch_layers,
-                                                     d_fft=pitch_d_fft, dropout=pitch_dropout, **common)
-        self.pitch_cond_pred = SeriesPredictor(d_model=pitch_cond_d_model, n_heads=pitch_cond_n_heads,
-                                               layers=pitch_cond_layers, d_fft=pitch_cond_d_fft,
-                                               dropout=pitch_cond_dropout, out_dim=pitch_cond_output_dims, **common)
-        self.energy_pred = SeriesPredictor(d_model=energy_d_model, n_heads=energy_n_heads, layers=energy_layers,
-                                           d_fft=energy_d_fft, dropout=energy_dropout, **common)
-        self.embedding = nn.Embedding(num_embeddings=num_chars, embedding_dim=d_model)
-        wide = d_model + speaker_emb_dims
-        self.prenet = ForwardTransformer(heads=prenet_heads, dropout=prenet_dropout, conv1_kernel=conv1_kernel,
-                                         conv2_kernel=conv2_kernel, d_model=wide, d_fft=prenet_fft,
-                                         layers=prenet_layers)
-        self.postnet = ForwardTransformer(heads=postnet_heads, dropout=postnet_dropout, conv1_kernel=conv1_kernel,
-                                          conv2_kernel=conv2_kernel, d_model=wide, d_fft=postnet_fft,
-                                          layers=postnet_layers)
-        self.lin = nn.Linear(wide, n_mels)
+        shared = {k: hp[k] for k in ('num_chars', 'conv1_kernel', 'conv2_kernel', 'speaker_emb_dims')}
+
+        def predictor(kind, prefix, **more):
+            return kind(d_model=hp[prefix + '_d_model'], n_heads=hp[prefix + '_n_heads'], layers=hp[prefix + '_layers'],
+                        d_fft=hp[prefix + '_d_fft'], dropout=hp[prefix + '_dropout'], **shared, **more)
+
+        wide = hp['d_model'] + hp['speaker_emb_dims']
+
+        def trunk(prefix):
+            return ForwardTransformer(d_model=wide, heads=hp[prefix + '_heads'], d_fft=hp[prefix + '_fft'],
+                                      layers=hp[prefix + '_layers'], dropout=hp[prefix + '_dropout'],
+                                      conv1_kernel=hp['conv1_kernel'], conv2_kernel=hp['conv2_kernel'])
+
+        # registration order = the reference's (it fixes the state_dict key order)
+        self.dur_pred = predictor(ConditionalSeriesPredictor, 'durpred')
+        self.pitch_pred = predictor(ConditionalSeriesPredictor, 'pitch')
+        self.pitch_cond_pred = predictor(SeriesPredictor, 'pitch_cond', out_dim=hp['pitch_cond_output_dims'])
+        self.energy_pred = predictor(SeriesPredictor, 'energy')
+        self.embedding = nn.Embedding(hp['num_chars'], hp['d_model'])
+        self.prenet = trunk('prenet')
+        self.postnet = trunk('postnet')
+        self.lin = nn.Linear(wide, hp['n_mels'])
         self.register_buffer('step', torch.zeros(1, dtype=torch.long))
-        self.pitch_strength = pitch_strength
-        self.energy_strength = energy_strength
+        self.pitch_strength = hp['pitch_strength']
+        self.energy_strength = hp['energy_strength']
         self.pitch_proj = nn.Conv1d(1, wide, kernel_size=3, padding=1)
         self.energy_proj = nn.Conv1d(1, wide, kernel_size=3, padding=1)
 

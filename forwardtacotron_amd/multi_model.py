@@ -80,49 +80,49 @@ class ConditionalSeriesPredictor(nn.Module):
 class MultiForwardTacotron(nn.Module):
     """Drop-in for models/multi_forward_tacotron.py:96-323."""
 
-    def __init__(self,
-                 embed_dims: int, series_embed_dims: int, num_chars: int,
-                 durpred_conv_dims: int, durpred_rnn_dims: int, durpred_dropout: float,
-                 pitch_conv_dims: int, pitch_rnn_dims: int, pitch_dropout: float, pitch_strength: float,
-                 pitch_cond_conv_dims: int, pitch_cond_rnn_dims: int, pitch_cond_dropout: float,
-                 energy_conv_dims: int, energy_rnn_dims: int, energy_dropout: float, energy_strength: float,
-                 rnn_dims: int, prenet_dims: int, prenet_k: int, postnet_num_highways: int,
-                 prenet_dropout: float, postnet_dims: int, postnet_k: int, prenet_num_highways: int,
-                 postnet_dropout: float, n_mels: int, speaker_emb_dims: int, pitch_cond_emb_dims: int,
-                 pitch_cond_categorical_dims: int, padding_value=PAD_VALUE):
+    # Constructor keywords = the keys of config['multi_forward_tacotron']['model'] (+ num_chars, n_mels), exactly the
+    # reference's (multi_forward_tacotron.py:98-129).
+    _KEYS = ('embed_dims', 'series_embed_dims', 'num_chars', 'rnn_dims', 'n_mels', 'speaker_emb_dims',
+             'pitch_cond_emb_dims', 'pitch_cond_categorical_dims', 'pitch_strength', 'energy_strength',
+             'prenet_dims', 'prenet_k', 'prenet_num_highways', 'prenet_dropout',
+             'postnet_dims', 'postnet_k', 'postnet_num_highways', 'postnet_dropout') + tuple(
+        f'{p}_{k}' for p in ('durpred', 'pitch', 'pitch_cond', 'energy') for k in ('conv_dims', 'rnn_dims', 'dropout'))
+
+    def __init__(self, padding_value=PAD_VALUE, **hp):
         super().__init__()
-        self.rnn_dims = rnn_dims
+        missing = [k for k in self._KEYS if k not in hp]
+        extra = [k for k in hp if k not in self._KEYS]
+        if missing or extra:
+            raise TypeError(f'MultiForwardTacotron(): missing {missing}, unexpected {extra}')
+        self.rnn_dims = hp['rnn_dims']
         self.padding_value = padding_value
-        self.embedding = nn.Embedding(num_chars, embed_dims)
+        E, P, Q, S = hp['embed_dims'], hp['prenet_dims'], hp['postnet_dims'], hp['speaker_emb_dims']
+        self.embedding = nn.Embedding(hp['num_chars'], E)
         self.lr = LengthRegulator()
-        # NB (reference quirk, multi_forward_tacotron.py:135-157): speaker_emb_dims is NOT forwarded to the
-        # predictors, they keep their default of 256.
-        self.dur_pred = ConditionalSeriesPredictor(num_chars=num_chars, emb_dim=series_embed_dims,
-                                                   conv_dims=durpred_conv_dims, rnn_dims=durpred_rnn_dims,
-                                                   cond_emb_dims=pitch_cond_emb_dims, dropout=durpred_dropout)
-        self.pitch_cond_pred = SeriesPredictor(num_chars=num_chars, emb_dim=series_embed_dims,
-                                               conv_dims=pitch_cond_conv_dims, rnn_dims=pitch_cond_rnn_dims,
-                                               dropout=pitch_cond_dropout, out_dim=pitch_cond_categorical_dims)
-        self.pitch_pred = ConditionalSeriesPredictor(num_chars=num_chars, emb_dim=series_embed_dims,
-                                                     conv_dims=pitch_conv_dims, rnn_dims=pitch_rnn_dims,
-                                                     cond_emb_dims=pitch_cond_emb_dims, dropout=pitch_dropout)
-        self.energy_pred = SeriesPredictor(num_chars=num_chars, emb_dim=series_embed_dims,
-                                           conv_dims=energy_conv_dims, rnn_dims=energy_rnn_dims,
-                                           dropout=energy_dropout)
-        self.prenet = CBHG(K=prenet_k, in_channels=embed_dims, channels=prenet_dims,
-                           proj_channels=[prenet_dims, embed_dims], num_highways=prenet_num_highways,
-                           dropout=prenet_dropout)
-        self.lstm = LSTM(2 * prenet_dims + speaker_emb_dims, rnn_dims)
-        self.lin = nn.Linear(2 * rnn_dims, n_mels)
+
+        def predictor(kind, prefix, **more):
+            # NB (reference quirk, multi_forward_tacotron.py:135-157): speaker_emb_dims is NOT forwarded to the
+            # predictors, they keep their default of 256.
+            return kind(num_chars=hp['num_chars'], emb_dim=hp['series_embed_dims'], conv_dims=hp[prefix + '_conv_dims'],
+                        rnn_dims=hp[prefix + '_rnn_dims'], dropout=hp[prefix + '_dropout'], **more)
+
+        # registration order = the reference's (it fixes the state_dict key order)
+        self.dur_pred = predictor(ConditionalSeriesPredictor, 'durpred', cond_emb_dims=hp['pitch_cond_emb_dims'])
+        self.pitch_cond_pred = predictor(SeriesPredictor, 'pitch_cond', out_dim=hp['pitch_cond_categorical_dims'])
+        self.pitch_pred = predictor(ConditionalSeriesPredictor, 'pitch', cond_emb_dims=hp['pitch_cond_emb_dims'])
+        self.energy_pred = predictor(SeriesPredictor, 'energy')
+        self.prenet = CBHG(K=hp['prenet_k'], in_channels=E, channels=P, proj_channels=[P, E],
+                           num_highways=hp['prenet_num_highways'], dropout=hp['prenet_dropout'])
+        self.lstm = LSTM(2 * P + S, hp['rnn_dims'])
+        self.lin = nn.Linear(2 * hp['rnn_dims'], hp['n_mels'])
         self.register_buffer('step', torch.zeros(1, dtype=torch.long))
-        self.postnet = CBHG(K=postnet_k, in_channels=n_mels, channels=postnet_dims,
-                            proj_channels=[postnet_dims, n_mels], num_highways=postnet_num_highways,
-                            dropout=postnet_dropout)
-        self.post_proj = nn.Linear(2 * postnet_dims, n_mels, bias=False)
-        self.pitch_strength = pitch_strength
-        self.energy_strength = energy_strength
-        self.pitch_proj = nn.Conv1d(1, 2 * prenet_dims + speaker_emb_dims, kernel_size=3, padding=1)
-        self.energy_proj = nn.Conv1d(1, 2 * prenet_dims + speaker_emb_dims, kernel_size=3, padding=1)
+        self.postnet = CBHG(K=hp['postnet_k'], in_channels=hp['n_mels'], channels=Q, proj_channels=[Q, hp['n_mels']],
+                            num_highways=hp['postnet_num_highways'], dropout=hp['postnet_dropout'])
+        self.post_proj = nn.Linear(2 * Q, hp['n_mels'], bias=False)
+        self.pitch_strength = hp['pitch_strength']
+        self.energy_strength = hp['energy_strength']
+        self.pitch_proj = nn.Conv1d(1, 2 * P + S, kernel_size=3, padding=1)
+        self.energy_proj = nn.Conv1d(1, 2 * P + S, kernel_size=3, padding=1)
         self._nbt_flat = None
 
     def __repr__(self):
