@@ -88,12 +88,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # Rehearsal hook for a one-GPU box (never set by the driver): FT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and
+    # talks over gloo, so that the N > 1 code path (barriers, bucketed all-reduce, rank-0 reporting) can be exercised
+    # where RCCL cannot be (it refuses two ranks on one device).  The numbers of such a run mean nothing.
+    rehearsal = os.environ.get('FT_BENCH_REHEARSAL') == '1'
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
 
     from forwardtacotron_amd import data
     from forwardtacotron_amd.model import ForwardTacotron
@@ -115,6 +123,9 @@ def main():
 
     from forwardtacotron_amd import _lib as _ftlib, hip as _hip
     probe = {'shape': BANK_SHAPE, 'events': []}
+    if rehearsal and world > 1:
+        # several ranks share one GPU here: their persistent grids cannot all be co-resident
+        _ftlib.query('ft_rnn_set_persistent', 0)
 
     def measure():
         """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize."""
@@ -147,7 +158,7 @@ def main():
         return elapsed, o, bool(flag.item() > 0)
 
     dt, out, rnn_ok = measure()
-    rnn_persistent = True
+    rnn_persistent = not (rehearsal and world > 1)
     if not rnn_ok:
         # a persistent recurrence timed out on some rank (its workgroups were not co-resident, e.g. under heavy
         # contention): that run is invalid -- switch every rank to the per-timestep kernels and measure again

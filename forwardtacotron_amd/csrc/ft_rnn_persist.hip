@@ -686,6 +686,9 @@ int ft_rnn_status(const void* workspace, void* stream) {
     return FT_ERR_HIP;
   }
   if (flag != 0) {
+    // report once: the word is cleared so that a caller who switches to the per-step kernels (which never touch it)
+    // is not told about the same timeout again
+    (void)hipMemset(const_cast<void*>(workspace), 0, sizeof(flag));
     ft_set_error("persistent recurrence timed out waiting for another workgroup (grid not co-resident?); "
                  "set FT_RNN_PERSISTENT=0 to use the per-step kernels");
     return FT_ERR_HIP;

@@ -607,8 +607,14 @@ def check_rnn_status() -> None:
     (tests, smoke and bench call this; a training loop can call it every N steps)."""
     used = list(_rnn_ws_used)
     _rnn_ws_used.clear()
-    for ws in used:
-        _lib.call('ft_rnn_status', _p(ws), _stream())
+    first = None
+    for ws in used:                 # visit every workspace (each visit also clears a raised status word)
+        try:
+            _lib.call('ft_rnn_status', _p(ws), _stream())
+        except _lib.FtError as e:
+            first = first or e
+    if first is not None:
+        raise first
 
 
 def gru_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool):
