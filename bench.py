@@ -10,8 +10,10 @@ Tm=841, 19,320 valid frames on rank 0's seed), singlespeaker.yaml model, fp32, d
 inputs resident in HBM before the timed region.  Weak scaling: every rank draws its own bs=32 batch.
 
 Rank 0 prints ONE JSON line (driver contract) with two extra objects:
-  roofline     : exact-f32 MFMA roofline of the dominant kernel (the f32-MFMA GEMM/conv kernel), timed live
-                 with HIP events on the launch stream, plus whole-step achieved TFLOP/s in `step`
+  roofline     : MFMA roofline of the dominant GEMM launch (postnet conv bank forward), timed live with HIP events
+                 on its launch stream inside every timed step: algorithmic fp32 TFLOP/s against the f32 MFMA peak,
+                 and -- the kernel runs fp32 products as exact 3-way bf16 splits on the bf16 matrix pipe -- the
+                 executed bf16 rate against the dense bf16 peak; plus whole-step achieved TFLOP/s in `step`
   cpu_baseline : the CPU oracle (port of the reference step) timed on this box's host cores on a bounded
                  sample of the same workload (rank 0, N=1 only)
 """
