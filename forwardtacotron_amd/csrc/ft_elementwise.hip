@@ -1,6 +1,7 @@
 // Element-wise / data-movement kernels (HBM-bound): conv weight packing, embedding, highway gates,
 // maxpool, conditioning projections, layout changes, masked L1.  See include/fwdtaco_hip.h.
 #include "ft_common.h"
+#include "../../include/fwdtaco_hip.h"
 
 namespace {
 
@@ -24,6 +25,51 @@ __global__ void ft_pack_conv_wt_kernel(const float* __restrict__ w, float* __res
   long rem = idx - (long)j * Cout * Cin;     // ci*Cout + co
   int ci = (int)(rem / Cout), co = (int)(rem - (long)ci * Cout);
   wpt[idx] = w[((long)co * Cin + ci) * k + j];
+}
+
+// every pack / transpose of a model in one launch: one workgroup = one 32x32 (d0 x d1) tile of one tap of one entry
+// (entry found by bisecting tile_begin); dst straight from registers, dst_t through a padded LDS tile
+__global__ __launch_bounds__(256) void ft_pack_weights_kernel(const FtPackDesc* __restrict__ descs, int n) {
+  __shared__ float tile[32][33];
+  const long bid = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_begin <= bid) lo = mid; else hi = mid - 1;
+  }
+  const FtPackDesc d = descs[lo];
+  long t = bid - d.tile_begin;
+  const int n1 = (d.d1 + 31) >> 5, n0 = (d.d0 + 31) >> 5;
+  const int j1 = (int)(t % n1);
+  t /= n1;
+  const int j0 = (int)(t % n0), a = (int)(t / n0);
+  if (a >= d.k) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c1 = j1 * 32 + tx;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int c0 = j0 * 32 + ty + 8 * r;
+    v[r] = (c0 < d.d0 && c1 < d.d1) ? d.src[((long)c0 * d.d1 + c1) * d.k + a] : 0.f;
+  }
+  if (d.dst) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int c0 = j0 * 32 + ty + 8 * r;
+      if (c0 < d.d0 && c1 < d.d1) d.dst[((long)a * d.d0 + c0) * d.d1 + c1] = v[r];
+    }
+  }
+  if (d.dst_t) {     // block-uniform
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[ty + 8 * r][tx] = v[r];
+    __syncthreads();
+    const int o0 = j0 * 32 + tx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int o1 = j1 * 32 + ty + 8 * r;
+      if (o1 < d.d1 && o0 < d.d0) d.dst_t[((long)a * d.d1 + o1) * d.d0 + o0] = tile[tx][ty + 8 * r];
+    }
+  }
 }
 
 // ---- dropout (F.dropout, forward_tacotron.py:35 ; common_layers.py:106,110) -------------------------
@@ -429,6 +475,14 @@ int ft_conv_pack_weight_t(const float* w, float* wpt, int Cout, int Cin, int k, 
   hipLaunchKernelGGL(ft_pack_conv_wt_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w, wpt,
                      Cout, Cin, k);
   return ft_check_launch("conv_pack_weight_t");
+}
+
+int ft_pack_weights(const FtPackDesc* descs, int n, long total_tiles, void* stream) {
+  FT_REQUIRE(n >= 0 && total_tiles >= 0 && total_tiles < (1L << 31), "pack_weights: bad sizes");
+  if (n == 0 || total_tiles == 0) return FT_OK;
+  FT_REQUIRE(descs != nullptr, "pack_weights: null descriptor array");
+  hipLaunchKernelGGL(ft_pack_weights_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, descs, n);
+  return ft_check_launch("pack_weights");
 }
 
 int ft_dropout(const float* x, float* out, long n, float p, uint64_t seed, void* stream) {

@@ -181,10 +181,98 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------------------
+# per-step operand packs
+# ---------------------------------------------------------------------------------------------------
+class PackCache:
+    """Every re-laid-out copy of a model's weights the GEMM kernels consume -- tap-major conv packs [k,Cout,Cin],
+    their transposes [k,Cin,Cout], the contiguous per-bank concatenations of both, and W^T of every matrix -- kept in
+    persistent buffers and refreshed by ONE ft_pack_weights launch.  Weights change only at the optimizer step, so a
+    training step calls refresh() once up front instead of ~120 small per-layer launches spread over forward and
+    backward.  Only valid between a refresh() and the next weight update: the owner (trainer.TrainStep) installs it as
+    `hip.pack_cache` for the duration of one step and removes it afterwards; with no cache installed every wrapper
+    below packs on the fly as before.
+
+    mats: 2-D weights; convs: 3-D Conv1d weights used on their own; banks: lists of Conv1d weights (k = 1..K, equal
+    [C,Cin]) whose packs must sit back to back (CBHG conv bank)."""
+
+    def __init__(self, mats, convs, banks, device):
+        import struct
+        self.wp, self.wpt, self.t2d, self.bank = {}, {}, {}, {}
+        self._keep = []
+        descs = []
+        tiles = 0
+
+        def add(src, dst, dst_t, d0, d1, k):
+            nonlocal tiles
+            descs.append(struct.pack('PPPqiiii', src.data_ptr(), _p(dst) or 0, _p(dst_t) or 0, tiles, d0, d1, k, 0))
+            tiles += k * ((d0 + 31) // 32) * ((d1 + 31) // 32)
+
+        for w in mats:
+            _chk(w, 'w')
+            R, C = w.shape
+            wt = torch.empty(C, R, device=device, dtype=w.dtype)
+            self.t2d[(w.data_ptr(), R, C)] = wt
+            add(w, None, wt, R, C, 1)
+        for w in convs:
+            _chk(w, 'w')
+            Cout, Cin, k = w.shape
+            wp = torch.empty(k, Cout, Cin, device=device, dtype=w.dtype)
+            wpt = torch.empty(k, Cin, Cout, device=device, dtype=w.dtype)
+            self.wp[w.data_ptr()] = wp
+            self.wpt[w.data_ptr()] = wpt
+            add(w, wp, wpt, Cout, Cin, k)
+        for ws in banks:
+            C, Cin = ws[0].shape[0], ws[0].shape[1]
+            n = sum(w.shape[2] for w in ws) * C * Cin
+            wp_all = torch.empty(n, device=device, dtype=ws[0].dtype)
+            wpt_all = torch.empty(n, device=device, dtype=ws[0].dtype)
+            off = 0
+            for w in ws:
+                _chk(w, 'w')
+                k = w.shape[2]
+                add(w, wp_all[off:off + k * C * Cin], wpt_all[off:off + k * C * Cin], C, Cin, k)
+                off += k * C * Cin
+            self.bank[tuple(w.data_ptr() for w in ws)] = (wp_all, wpt_all)
+        self.n, self.tiles = len(descs), tiles
+        self.descs = torch.frombuffer(bytearray(b''.join(descs)), dtype=torch.uint8).to(device) if descs else None
+
+    def refresh(self) -> None:
+        if self.n:
+            _lib.call('ft_pack_weights', _p(self.descs), self.n, self.tiles, _stream())
+
+
+pack_cache: Optional[PackCache] = None
+
+
+def bank_packs(ws: Sequence[torch.Tensor], transposed: bool) -> torch.Tensor:
+    """back-to-back tap-major packs ([k,C,Cin], or [k,Cin,C] if transposed) of the members of a conv bank"""
+    if pack_cache is not None:
+        hit = pack_cache.bank.get(tuple(w.data_ptr() for w in ws))
+        if hit is not None:
+            return hit[1 if transposed else 0]
+    C, Cin = ws[0].shape[0], ws[0].shape[1]
+    out = torch.empty(sum(w.shape[2] for w in ws) * C * Cin, device=ws[0].device, dtype=ws[0].dtype)
+    off = 0
+    for w in ws:
+        k = w.shape[2]
+        n = k * C * Cin
+        if transposed:
+            conv_pack_weight_t(w, out=out[off:off + n].view(k, Cin, C))
+        else:
+            conv_pack_weight(w, out=out[off:off + n].view(k, C, Cin))
+        off += n
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 # channels-last conv
 # ---------------------------------------------------------------------------------------------------
 def conv_pack_weight(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[Cout,Cin,k] -> tap-major [k,Cout,Cin]"""
+    if out is None and pack_cache is not None:
+        hit = pack_cache.wp.get(w.data_ptr())
+        if hit is not None:
+            return hit
     _chk(w, 'w')
     Cout, Cin, k = w.shape
     wp = out if out is not None else torch.empty(k, Cout, Cin, device=w.device, dtype=w.dtype)
@@ -232,6 +320,10 @@ bank_probe = None
 
 def conv_pack_weight_t(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[Cout,Cin,k] -> transposed tap-major [k,Cin,Cout] (weight operand of the data gradient in the NT form)"""
+    if out is None and pack_cache is not None:
+        hit = pack_cache.wpt.get(w.data_ptr())
+        if hit is not None:
+            return hit
     _chk(w, 'w')
     Cout, Cin, k = w.shape
     wpt = out if out is not None else torch.empty(k, Cin, Cout, device=w.device, dtype=w.dtype)
@@ -261,13 +353,7 @@ def conv_bank_bwd_data(dy: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, C
     dx = torch.empty(B, T, Cin, device=dy.device, dtype=dy.dtype)
     flag = 0
     if NT_GRADS and ws is not None and C % 4 == 0:
-        wpt_all = torch.empty_like(wp_all)
-        off = 0
-        for i, w in enumerate(ws):
-            n = (i + 1) * C * Cin
-            conv_pack_weight_t(w, out=wpt_all[off:off + n].view(i + 1, Cin, C))
-            off += n
-        wp_all, flag = wpt_all, 1
+        wp_all, flag = bank_packs(ws, True), 1
     _lib.call('ft_conv_bank_bwd_data', _p(dy), K * C, _p(wp_all), _p(dx), Cin, B, T, Cin, C, K, Tbuf, flag, _stream())
     return dx
 
@@ -558,6 +644,10 @@ def transpose_pad_bwd(dout: torch.Tensor, T: int) -> torch.Tensor:
 def transpose2d(x: torch.Tensor) -> torch.Tensor:
     """[R,C] -> [C,R] (used for W_hh^T in BPTT)."""
     R, C = x.shape
+    if pack_cache is not None:
+        hit = pack_cache.t2d.get((x.data_ptr(), R, C))
+        if hit is not None:
+            return hit
     return transpose_pad_fwd(x.view(1, R, C), R, 0.0).view(C, R)
 
 

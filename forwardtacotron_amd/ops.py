@@ -224,12 +224,7 @@ class ConvBankFn(Function):
         ws = params[:K]
         B, T, Cin = x.shape
         C = ws[0].shape[0]
-        wp_all = torch.empty(C * Cin * K * (K + 1) // 2, device=x.device, dtype=x.dtype)
-        off = 0
-        for i, w in enumerate(ws):
-            n = (i + 1) * C * Cin
-            H.conv_pack_weight(w, out=wp_all[off:off + n].view(i + 1, C, Cin))
-            off += n
+        wp_all = H.bank_packs(ws, False)
         ybank = H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T + 1)
         z, mean, rstd = H.bn_train_fwd(ybank, gamma, beta, running_mean, running_var, Tout=T, group=C)
         out = H.maxpool2_fwd(z)

@@ -47,6 +47,25 @@ class TrainStep:
         self.reducer.streams.add(self.wgrad_stream)
         self.sink = ops.GradSink({p.data_ptr(): (i, p.grad) for i, p in enumerate(self.flat.params)},
                                  stream=self.wgrad_stream, on_write=self.reducer.notify)
+        self.packs: Optional[H.PackCache] = None
+        self._packs_base = 0
+
+    def _weight_packs(self) -> H.PackCache:
+        """the re-laid-out weight copies of this model (hip.PackCache), rebuilt only if the flat buffer moved"""
+        if self.packs is None or self._packs_base != self.flat.flat.data_ptr():
+            in_bank, banks = set(), []
+            for mod in self.model.modules():
+                if hasattr(mod, 'conv1d_bank'):
+                    ws = [m.conv.weight for m in mod.conv1d_bank]
+                    banks.append(ws)
+                    in_bank.update(id(w) for w in ws)
+            emb = {id(p) for m in self.model.modules() if isinstance(m, torch.nn.Embedding) for p in m.parameters()}
+            ps = [p for p in self.flat.params if p.dtype == torch.float32 and id(p) not in emb]
+            self.packs = H.PackCache(mats=[p for p in ps if p.dim() == 2],
+                                     convs=[p for p in ps if p.dim() == 3 and id(p) not in in_bank],
+                                     banks=banks, device=self.flat.flat.device)
+            self._packs_base = self.flat.flat.data_ptr()
+        return self.packs
 
     # -- state for checkpoints: same content as torch.optim.Adam's (exp_avg / exp_avg_sq / step), flat
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -88,16 +107,22 @@ class TrainStep:
             em = (torch.rand(batch['x'].size()) > c['energy_zoneout']).to(dev).float()
             batch['pitch'] = batch['pitch'] * pm
             batch['energy'] = batch['energy'] * em
-        pred = model(batch)
-        L = self.losses(pred, batch, pitch_target, energy_target)
-        self.flat.zero_grad()
-        self.reducer.start()
-        self.sink.begin_step()
-        ops.set_grad_sink(self.sink)
+        packs = self._weight_packs()
+        packs.refresh()                     # every conv pack / weight transpose of this step, one launch
+        H.pack_cache = packs
         try:
-            L['loss'].backward()
+            pred = model(batch)
+            L = self.losses(pred, batch, pitch_target, energy_target)
+            self.flat.zero_grad()
+            self.reducer.start()
+            self.sink.begin_step()
+            ops.set_grad_sink(self.sink)
+            try:
+                L['loss'].backward()
+            finally:
+                ops.set_grad_sink(None)
         finally:
-            ops.set_grad_sink(None)
+            H.pack_cache = None
         torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         self.reducer.finish()
         self.optimizer_step()

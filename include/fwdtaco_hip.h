@@ -64,6 +64,20 @@ int ft_conv_pack_weight(const float* w, float* wp, int Cout, int Cin, int k, voi
 /* transposed tap-major pack wpt[k][Cin][Cout] for the data gradients (`wp_transposed` = 1 below): the contraction
  * index Cout becomes contiguous, which lets the gradient GEMM run in the NT form (see `w_transposed`) */
 int ft_conv_pack_weight_t(const float* w, float* wpt, int Cout, int Cin, int k, void* stream);
+/* All of a model's operand re-layouts in ONE launch (weights change once per optimizer step, so a training step
+ * refreshes every pack / transpose up front instead of one small launch per layer).  Entry e re-lays
+ * src [d0][d1][k] (a Conv1d weight [Cout][Cin][k]; a Linear / RNN weight [out_f][in_f] has k = 1) as
+ * dst [k][d0][d1] (ft_conv_pack_weight) and / or dst_t [k][d1][d0] (ft_conv_pack_weight_t; the transpose of a
+ * matrix); either may be NULL.  tile_begin = sum over earlier entries of k*ceil(d0/32)*ceil(d1/32), ascending;
+ * `descs` is a DEVICE array of n entries, total_tiles the sum over all entries. */
+typedef struct FtPackDesc {
+  const float* src;
+  float* dst;
+  float* dst_t;
+  long tile_begin;
+  int d0, d1, k, reserved;
+} FtPackDesc;
+int ft_pack_weights(const FtPackDesc* descs, int n, long total_tiles, void* stream);
 int ft_conv1d_fwd(const float* x, long ldx, const float* wp, const float* scale, const float* shift, float* y,
                   long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, int accumulate,
                   void* stream);

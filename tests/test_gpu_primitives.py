@@ -69,6 +69,39 @@ def test_large_gemm_split_path_is_fp32_accurate(H):
     assert rel_err(yc, refc) < 2e-6
 
 
+def test_pack_weights_one_launch(H):
+    """ft_pack_weights: every pack / transpose in one launch == the per-layer packs, bit for bit (pure data movement);
+    ragged dims exercise the tile edges; with the cache installed the wrappers hand out the cached buffers."""
+    g = torch.Generator().manual_seed(11)
+    mats = [dev(torch.randn(r, c, generator=g)) for r, c in ((64, 32), (33, 65), (1, 7), (384, 80), (100, 257))]
+    convs = [dev(torch.randn(co, ci, k, generator=g)) for co, ci, k in ((40, 33, 5), (32, 64, 1), (7, 3, 16))]
+    banks = [[dev(torch.randn(24, 17, k, generator=g)) for k in range(1, 6)],
+             [dev(torch.randn(8, 8, k, generator=g)) for k in range(1, 3)]]
+    cache = H.PackCache(mats, convs, banks, mats[0].device)
+    cache.refresh()
+    torch.cuda.synchronize()
+    for w in mats:
+        assert torch.equal(cache.t2d[(w.data_ptr(), *w.shape)], w.t().contiguous())
+    for w in convs:
+        assert torch.equal(cache.wp[w.data_ptr()], w.permute(2, 0, 1).contiguous())
+        assert torch.equal(cache.wpt[w.data_ptr()], w.permute(2, 1, 0).contiguous())
+    for ws in banks:
+        wp_all, wpt_all = cache.bank[tuple(w.data_ptr() for w in ws)]
+        assert torch.equal(wp_all, torch.cat([w.permute(2, 0, 1).reshape(-1) for w in ws]))
+        assert torch.equal(wpt_all, torch.cat([w.permute(2, 1, 0).reshape(-1) for w in ws]))
+        assert torch.equal(H.bank_packs(ws, False), wp_all) and torch.equal(H.bank_packs(ws, True), wpt_all)
+    try:
+        H.pack_cache = cache
+        assert H.transpose2d(mats[1]).data_ptr() == cache.t2d[(mats[1].data_ptr(), 33, 65)].data_ptr()
+        assert H.conv_pack_weight(convs[0]).data_ptr() == cache.wp[convs[0].data_ptr()].data_ptr()
+        assert H.conv_pack_weight_t(convs[0]).data_ptr() == cache.wpt[convs[0].data_ptr()].data_ptr()
+        assert H.bank_packs(banks[0], True).data_ptr() == cache.bank[tuple(w.data_ptr() for w in banks[0])][1].data_ptr()
+        other = dev(torch.randn(5, 6, generator=g))
+        assert torch.equal(H.transpose2d(other), other.t().contiguous())      # miss -> packed on the fly
+    finally:
+        H.pack_cache = None
+
+
 def test_linear_multi(H):
     g = torch.Generator().manual_seed(3)
     x = torch.randn(3, 50, 24, generator=g)
