@@ -470,16 +470,30 @@ struct TNPlan {
   int tm, tn, S, rows_per_split;
 };
 
-TNPlan plan_tn(const FtGemmTNTask& t) {
+// FT_GEMM_B3_TN: 0 = weight gradients never take the bf16-split path, 1 = every tile size does, default: 128x128 only
+int tn_b3_mode() {
+  static const int mode = [] {
+    const char* e = getenv("FT_GEMM_B3_TN");
+    return e ? (e[0] == '1' ? 2 : (e[0] == '0' ? 0 : 1)) : 1;
+  }();
+  return ft_gemm_b3_enabled() ? mode : 0;
+}
+
+// split path usable (aligned operands): its 128x128 tile runs ~1.35x the f32 kernels' rate, so it is preferred whenever
+// tiles x split-K can still fill the chip -- the extra slabs it needs cost a few microseconds of HBM traffic
+TNPlan plan_tn(const FtGemmTNTask& t, bool b3_ok) {
   TNPlan p;
   const int nz = t.nz > 1 ? t.nz : 1;
-  bool small = ((long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128) * t.taps * nz < 64) || t.M <= 64 || t.N <= 64;
+  long maxs = (t.R + 4 * BK - 1) / (4 * BK);      // at least 128 rows per split
+  if (maxs < 1) maxs = 1;
+  const long tiles128 = (long)ft_cdiv(t.M, 128) * ft_cdiv(t.N, 128) * t.taps * nz;
+  bool small = tiles128 < 64 || t.M <= 64 || t.N <= 64;
+  // ... as long as every split still has >= 1024 rows to amortise its prologue and its slab
+  if (b3_ok && tn_b3_mode() >= 1 && t.M > 64 && t.N > 64 && tiles128 * (t.R / 1024) >= 256) small = false;
   p.tm = p.tn = small ? 1 : 2;
   int bm = 64 * p.tm;
   long tiles = (long)ft_cdiv(t.M, bm) * ft_cdiv(t.N, bm) * t.taps * nz;
   long want = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
-  long maxs = (t.R + 4 * BK - 1) / (4 * BK);      // at least 128 rows per split
-  if (maxs < 1) maxs = 1;
   long S = want < maxs ? want : maxs;
   if (S > 65535 / ((long)t.taps * nz)) S = 65535 / ((long)t.taps * nz);
   if (S < 1) S = 1;
@@ -538,8 +552,9 @@ bool ft_gemm_b3_enabled() {
 }
 
 size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& t) {
-  TNPlan p = plan_tn(t);
-  return (size_t)p.S * t.taps * (t.nz > 1 ? t.nz : 1) * t.M * t.N;
+  // the query does not know the operands' alignment yet: cover both plans the launcher may pick
+  const TNPlan p0 = plan_tn(t, false), p1 = plan_tn(t, true);
+  return (size_t)(p0.S > p1.S ? p0.S : p1.S) * t.taps * (t.nz > 1 ? t.nz : 1) * t.M * t.N;
 }
 
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream) {
@@ -632,23 +647,19 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   FT_REQUIRE(t.nz1 >= 1 && t.nz % t.nz1 == 0, "gemm_tn: bad batch split");
   t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0) && (t.sA0 % 4 == 0) && (t.sA1 % 4 == 0);
   t.b_vec = (t.ldb % 4 == 0) && (((uintptr_t)t.B) % 16 == 0) && (t.sB0 % 4 == 0) && (t.sB1 % 4 == 0);
-  TNPlan p = plan_tn(t);
+  const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
+  TNPlan p = plan_tn(t, fast);
   size_t need = (size_t)p.S * t.taps * t.nz * t.M * t.N;
   FT_REQUIRE(workspace && workspace_floats >= need, "gemm_tn: workspace too small (%zu < %zu floats)",
              workspace_floats, need);
   const int bm = 64 * p.tm;
   dim3 grid(ft_cdiv(t.M, bm), ft_cdiv(t.N, bm), p.S * t.taps * t.nz);
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_tn: grid too large");
-  const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
   GemmLog log;
   log.begin(stream);
-  // measured (profiles/r01c_gemm_report_f32.txt vs r01c_gemm_report_b3_all.txt): the transposing staging of the bf16-split TN form costs what its MFMAs
-  // save (128-tiles: 104 vs 104 TF) and loses on the 64-tiles (43 vs 62 TF), so it stays opt-in (FT_GEMM_B3_TN=1)
-  static const bool b3_tn = [] {
-    const char* e = getenv("FT_GEMM_B3_TN");
-    return e && e[0] == '1';
-  }();
-  const bool b3 = fast && b3_tn && ft_gemm_b3_enabled();
+  // bf16-split TN form (r-pair packed LDS tiles, ft_gemm_b3.hip): on by default for the 128x128 tile; the 64x64 tile
+  // has twice the staging per MFMA and stays on the f32 kernel unless FT_GEMM_B3_TN=1
+  const bool b3 = fast && (tn_b3_mode() == 2 || (tn_b3_mode() == 1 && p.tm == 2));
   if (b3) {
     (void)ft_launch_gemm_tn_b3(t, workspace, p.S, p.rows_per_split, p.tm, grid, stream);
   } else if (p.tm == 2) {

@@ -239,20 +239,23 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
 
 // ---------------------------------------------------------------------------------------------------
 // TN (weight gradients): slab[z][m][n] = sum_{r in slice} A[map_a(r)][m] * B[map_b,tap(r)][n].  The contraction index
-// is the ROW index of both operands, so the staging transposes on the fly: a thread fetches a 4(r) x 4(m) block as
-// four 16-B loads (coalesced along m), regroups it in registers into four 4(r)-vectors, splits them and writes three
-// 8-B pieces per output row -- the LDS tiles come out [m][plane][32 r], the same fragment layout as the rows kernel.
+// r is the ROW index of both operands, while a bf16 MFMA fragment wants 8 consecutive r of one column in a lane.  The
+// LDS tiles are therefore kept r-PAIR packed: word [plane][r/2][m] holds the bf16 pieces of rows r (low half) and r+1
+// (high half) of column m.  Staging stays coalesced on both sides -- a thread fetches rows r, r+1 of 4 adjacent columns
+// (two 16-B loads), splits them and writes one 16-B piece per plane, conflict-free -- and a fragment is four 4-B reads
+// one pair-row apart (row stride = BM + 8 words puts the two k-halves of a wave 32 banks apart).  [The first version
+// wrote [m][plane][r] rows with 8-B pieces 832 B apart: a 16-way bank conflict that cost what the MFMAs saved.]
 template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, float* slab, int S, int rows_per_split) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int MQ = BM / 4, NQ = BN / 4;            // column quads per tile
-  constexpr int ABLK = MQ * 8, BBLK = NQ * 8;        // 4x4 blocks per stage (8 row quads of 4)
-  constexpr int PA = (ABLK + BBLK <= 256) ? 1 : ABLK / 256;     // blocks per thread
-  constexpr int PB = (ABLK + BBLK <= 256) ? 1 : BBLK / 256;
-  constexpr bool SHARED = ABLK + BBLK <= 256;        // 64x64 tile: threads 0..127 stage A, 128..255 stage B
-  __shared__ __attribute__((aligned(16))) unsigned short smem[(BM + BN) * RS];
-  unsigned short* As = smem;
-  unsigned short* Bs = smem + BM * RS;
+  constexpr int QA = 256 / MQ, QB = 256 / NQ;        // pair-rows covered by one pass of the 256 threads
+  constexpr int PA = 16 / QA, PB = 16 / QB;          // passes per stage (BK = 32 rows = 16 pair-rows)
+  constexpr int RWA = BM + 8, RWB = BN + 8;          // pair-row stride in 32-bit words
+  constexpr int PLA = 16 * RWA, PLB = 16 * RWB;      // plane stride
+  __shared__ __attribute__((aligned(16))) unsigned smem[3 * PLA + 3 * PLB];
+  unsigned* As = smem;
+  unsigned* Bs = smem + 3 * PLA;
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int zts = blockIdx.z / S, s = blockIdx.z - zts * S;
@@ -274,96 +277,88 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
   const int ashift = T.amap.shift0 + tap * T.amap.shift_step;
   const int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
 
-  // staging role of this thread: which operand, which column quad, which row quad
-  const bool doA = SHARED ? tid < ABLK : true;
-  const bool doB = SHARED ? tid >= ABLK : true;
-  const int ta = SHARED ? tid : tid;                 // block index within A (p-th block: ta + 256 p)
-  const int tb = SHARED ? tid - ABLK : tid;
-  // (item, t) of the first of the 4 rows of every block, tracked incrementally (stages come in order, 32 rows apart)
-  int a_b[PA][4], a_t[PA][4], b_b[PB][4], b_t[PB][4];
+  const int amq = tid % MQ, aq0 = tid / MQ;          // this thread's column quad / first pair-row, per operand
+  const int bmq = tid % NQ, bq0 = tid / NQ;
+  const int am = m0 + 4 * amq, bn = n0 + 4 * bmq;
+  const bool am_ok = am < tM, bn_ok = bn < tN;
+  // (item, t) of every row this thread stages, tracked incrementally (stages come in order, BK rows apart)
+  int a_b[PA][2], a_t[PA][2], b_b[PB][2], b_t[PB][2];
 #pragma unroll
   for (int p = 0; p < PA; ++p)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = r_begin + 4 * ((ta + 256 * p) / MQ) + i;
+    for (int i = 0; i < 2; ++i) {
+      const int r = r_begin + 2 * (aq0 + QA * p) + i;
       a_b[p][i] = r / aTlog;
       a_t[p][i] = r - a_b[p][i] * aTlog;
     }
 #pragma unroll
   for (int p = 0; p < PB; ++p)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int r = r_begin + 4 * ((tb + 256 * p) / NQ) + i;
+    for (int i = 0; i < 2; ++i) {
+      const int r = r_begin + 2 * (bq0 + QB * p) + i;
       b_b[p][i] = r / bTlog;
       b_t[p][i] = r - b_b[p][i] * bTlog;
     }
   int r_next = r_begin;
 
-  float4 ra[PA][4], rb[PB][4];
+  float4 ra[PA][2], rb[PB][2];
   auto load_stage = [&]() {
-    if (doA) {
 #pragma unroll
-      for (int p = 0; p < PA; ++p) {
-        const int blk = ta + 256 * p, mq = blk % MQ, rq = blk / MQ;
-        const int am = m0 + 4 * mq;
+    for (int p = 0; p < PA; ++p)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = r_next + 4 * rq + i;
-          const int ts = a_t[p][i] + ashift;
-          const bool ok = (r < r_end) & (ts >= 0) & (ts < aTvalid) & (am < tM);
-          ra[p][i] = ld4_sel(TA + ((long)a_b[p][i] * abst + (long)ts * atst) * lda + am, TA, ok);
-          a_t[p][i] += BK;
-          while (a_t[p][i] >= aTlog) {
-            a_t[p][i] -= aTlog;
-            ++a_b[p][i];
-          }
+      for (int i = 0; i < 2; ++i) {
+        const int r = r_next + 2 * (aq0 + QA * p) + i;
+        const int ts = a_t[p][i] + ashift;
+        const bool ok = (r < r_end) & (ts >= 0) & (ts < aTvalid) & am_ok;
+        ra[p][i] = ld4_sel(TA + ((long)a_b[p][i] * abst + (long)ts * atst) * lda + am, TA, ok);
+        a_t[p][i] += BK;
+        while (a_t[p][i] >= aTlog) {
+          a_t[p][i] -= aTlog;
+          ++a_b[p][i];
         }
       }
-    }
-    if (doB) {
 #pragma unroll
-      for (int p = 0; p < PB; ++p) {
-        const int blk = tb + 256 * p, nq = blk % NQ, rq = blk / NQ;
-        const int bn = n0 + 4 * nq;
+    for (int p = 0; p < PB; ++p)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int r = r_next + 4 * rq + i;
-          const int ts = b_t[p][i] + bshift;
-          const bool ok = (r < r_end) & (ts >= 0) & (ts < bTvalid) & (bn < tN);
-          rb[p][i] = ld4_sel(TB + ((long)b_b[p][i] * bbst + (long)ts * btst) * ldb + bn, TB, ok);
-          b_t[p][i] += BK;
-          while (b_t[p][i] >= bTlog) {
-            b_t[p][i] -= bTlog;
-            ++b_b[p][i];
-          }
+      for (int i = 0; i < 2; ++i) {
+        const int r = r_next + 2 * (bq0 + QB * p) + i;
+        const int ts = b_t[p][i] + bshift;
+        const bool ok = (r < r_end) & (ts >= 0) & (ts < bTvalid) & bn_ok;
+        rb[p][i] = ld4_sel(TB + ((long)b_b[p][i] * bbst + (long)ts * btst) * ldb + bn, TB, ok);
+        b_t[p][i] += BK;
+        while (b_t[p][i] >= bTlog) {
+          b_t[p][i] -= bTlog;
+          ++b_b[p][i];
         }
       }
-    }
     r_next += BK;
   };
+  // rows (even, odd) of 4 columns -> three 16-B pieces of pair-packed bf16
+  auto store_pair = [&](unsigned* dst, int plane_stride, const float4& ev, const float4& od) {
+    const float e[4] = {ev.x, ev.y, ev.z, ev.w}, o[4] = {od.x, od.y, od.z, od.w};
+    uint4 hi, mid, lo;
+    unsigned* ph = reinterpret_cast<unsigned*>(&hi);
+    unsigned* pm = reinterpret_cast<unsigned*>(&mid);
+    unsigned* pl = reinterpret_cast<unsigned*>(&lo);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned he = __float_as_uint(e[c]) & 0xFFFF0000u, ho = __float_as_uint(o[c]) & 0xFFFF0000u;
+      const float e1 = e[c] - __uint_as_float(he), o1 = o[c] - __uint_as_float(ho);
+      const unsigned me = __float_as_uint(e1) & 0xFFFF0000u, mo = __float_as_uint(o1) & 0xFFFF0000u;
+      const float e2 = e1 - __uint_as_float(me), o2 = o1 - __uint_as_float(mo);
+      ph[c] = ho | (he >> 16);
+      pm[c] = mo | (me >> 16);
+      pl[c] = (__float_as_uint(o2) & 0xFFFF0000u) | (__float_as_uint(e2) >> 16);
+    }
+    *reinterpret_cast<uint4*>(dst) = hi;
+    *reinterpret_cast<uint4*>(dst + plane_stride) = mid;
+    *reinterpret_cast<uint4*>(dst + 2 * plane_stride) = lo;
+  };
   auto store_stage = [&]() {
-    if (doA) {
 #pragma unroll
-      for (int p = 0; p < PA; ++p) {
-        const int blk = ta + 256 * p, mq = blk % MQ, rq = blk / MQ;
-        unsigned short* base = As + (4 * mq) * RS + 4 * rq;
-        store_split(base + 0 * RS, make_float4(ra[p][0].x, ra[p][1].x, ra[p][2].x, ra[p][3].x));
-        store_split(base + 1 * RS, make_float4(ra[p][0].y, ra[p][1].y, ra[p][2].y, ra[p][3].y));
-        store_split(base + 2 * RS, make_float4(ra[p][0].z, ra[p][1].z, ra[p][2].z, ra[p][3].z));
-        store_split(base + 3 * RS, make_float4(ra[p][0].w, ra[p][1].w, ra[p][2].w, ra[p][3].w));
-      }
-    }
-    if (doB) {
+    for (int p = 0; p < PA; ++p) store_pair(As + (aq0 + QA * p) * RWA + 4 * amq, PLA, ra[p][0], ra[p][1]);
 #pragma unroll
-      for (int p = 0; p < PB; ++p) {
-        const int blk = tb + 256 * p, nq = blk % NQ, rq = blk / NQ;
-        unsigned short* base = Bs + (4 * nq) * RS + 4 * rq;
-        store_split(base + 0 * RS, make_float4(rb[p][0].x, rb[p][1].x, rb[p][2].x, rb[p][3].x));
-        store_split(base + 1 * RS, make_float4(rb[p][0].y, rb[p][1].y, rb[p][2].y, rb[p][3].y));
-        store_split(base + 2 * RS, make_float4(rb[p][0].z, rb[p][1].z, rb[p][2].z, rb[p][3].z));
-        store_split(base + 3 * RS, make_float4(rb[p][0].w, rb[p][1].w, rb[p][2].w, rb[p][3].w));
-      }
-    }
+    for (int p = 0; p < PB; ++p) store_pair(Bs + (bq0 + QB * p) * RWB + 4 * bmq, PLB, rb[p][0], rb[p][1]);
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -378,8 +373,9 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (r_begin < r_end) {
-    const unsigned short* ap = As + (wm * 32 * TM + l31) * RS + 8 * half;
-    const unsigned short* bp = Bs + (wn * 32 * TN + l31) * RS + 8 * half;
+    // fragment of sub-step ks: pair-rows 8 ks + 4 half + {0..3}, column (tile column) + l31
+    const unsigned* ap = As + 4 * half * RWA + wm * 32 * TM + l31;
+    const unsigned* bp = Bs + 4 * half * RWB + wn * 32 * TN + l31;
     const int nch = (r_end - r_begin + BK - 1) / BK;
     load_stage();
     store_stage();
@@ -392,13 +388,19 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            a[i][pl] = *reinterpret_cast<const bf16x8*>(ap + 32 * i * RS + 32 * pl + 16 * ks);
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned* q = ap + pl * PLA + 8 * ks * RWA + 32 * i;
+            const uint4 w = make_uint4(q[0], q[RWA], q[2 * RWA], q[3 * RWA]);
+            a[i][pl] = __builtin_bit_cast(bf16x8, w);
+          }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            b[j][pl] = *reinterpret_cast<const bf16x8*>(bp + 32 * j * RS + 32 * pl + 16 * ks);
+          for (int pl = 0; pl < 3; ++pl) {
+            const unsigned* q = bp + pl * PLB + 8 * ks * RWB + 32 * j;
+            const uint4 w = make_uint4(q[0], q[RWB], q[2 * RWB], q[3 * RWB]);
+            b[j][pl] = __builtin_bit_cast(bf16x8, w);
+          }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
