@@ -224,27 +224,47 @@ int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, l
 }
 
 // data gradient of the whole conv bank in ONE launch: dx[b,t,:] = sum_k sum_tap dy_k[b, t - tap + k/2, :] * W_k,tap
-// (K chained tasks accumulated in registers; member k's rows t >= Tvalid_k of dy are not part of its output)
+// (member k's rows t >= Tvalid_k of dy are not part of its output).  Chained: the K tasks are accumulated in registers.
+// With few output tiles (prenet: 4096 x 256 = 64 tiles of 128x128) a chain would leave 3/4 of the CUs idle, so there the
+// members run as K independent tasks into per-member partials and an ordered sum follows.
+static bool bank_bwd_partials(int B, int T, int Cin, int K) {
+  const long tiles = (long)ft_cdiv((long)B * T, 128) * ft_cdiv(Cin, 128);
+  return K >= 2 && Cin > 64 && (long)B * T > 64 && tiles < 192 && tiles * K >= 192;
+}
+
+size_t ft_conv_bank_bwd_data_workspace(int B, int T, int Cin, int K) {
+  return bank_bwd_partials(B, T, Cin, K) ? (size_t)K * B * T * Cin * sizeof(float) : 0;
+}
+
 int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
-                          int C, int K, int Tbuf, int wp_transposed, void* stream) {
+                          int C, int K, int Tbuf, int wp_transposed, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   FT_REQUIRE(K >= 1 && K <= FT_MAX_TASKS, "conv_bank_bwd_data: K=%d unsupported (max %d)", K, FT_MAX_TASKS);
   FT_REQUIRE(Tbuf == T || Tbuf == T + 1, "conv_bank_bwd_data: Tbuf must be T or T+1");
+  const bool partials = bank_bwd_partials(B, T, Cin, K);
+  if (partials)
+    FT_REQUIRE(workspace && workspace_bytes >= ft_conv_bank_bwd_data_workspace(B, T, Cin, K),
+               "conv_bank_bwd_data: workspace too small");
+  float* part = static_cast<float*>(workspace);
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   long woff = 0;
   for (int i = 0; i < K; ++i) {
     const int k = i + 1;
     FtGemmTask& t = b.t[i];
-    t.A = dy + (long)i * C; t.B = wp_all + woff; t.C = dx;
-    t.lda = lddy; t.ldb = wp_transposed ? C : Cin; t.ldc = lddx; t.b_tap_stride = (long)C * Cin;
+    t.A = dy + (long)i * C; t.B = wp_all + woff;
+    t.C = partials ? part + (long)i * B * T * Cin : dx;
+    t.lda = lddy; t.ldb = wp_transposed ? C : Cin; t.ldc = partials ? Cin : lddx; t.b_tap_stride = (long)C * Cin;
     t.M = B * T; t.N = Cin; t.K = C; t.taps = k;
     const int Tvalid = (k % 2 == 0) ? Tbuf : T;            // even kernels produce T+1 rows when the buffer has them
     FtRowMap m = {T > 0 ? T : 1, Tbuf, 1, Tvalid < Tbuf ? Tvalid : Tbuf, k / 2, -1};
     t.amap = m;
     woff += (long)k * C * Cin;
   }
-  b.chain = K;
-  return ft_launch_gemm_rows(&b, K, !wp_transposed, (hipStream_t)stream);
+  b.chain = partials ? 0 : K;
+  int rc = ft_launch_gemm_rows(&b, K, !wp_transposed, (hipStream_t)stream);
+  if (rc || !partials) return rc;
+  return ft_launch_slab_sum(part, dx, B * T, Cin, K, lddx, (hipStream_t)stream);
 }
 
 static FtGemmTNTask conv_bw_task(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T,

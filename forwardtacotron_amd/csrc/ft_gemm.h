@@ -76,3 +76,5 @@ bool ft_gemm_b3_enabled();
 int ft_launch_gemm_tn(const FtGemmTNTask& task, float* workspace, size_t workspace_floats,
                       hipStream_t stream);
 size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& task);
+// dst[m*ldm + n] = sum_{s<S} slab[s][m][n]  (fixed order)
+int ft_launch_slab_sum(const float* slab, float* dst, int M, int N, int S, long ldm, hipStream_t stream);

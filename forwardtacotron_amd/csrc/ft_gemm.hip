@@ -635,6 +635,14 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   return ft_check_launch("gemm_rows");
 }
 
+int ft_launch_slab_sum(const float* slab, float* dst, int M, int N, int S, long ldm, hipStream_t stream) {
+  long total = (long)M * N;
+  if (total == 0) return FT_OK;
+  hipLaunchKernelGGL(ft_splitk_reduce_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, stream, slab, dst, M, N, 1, S,
+                     ldm, 1L, 0L, 0, 1, 1, 0L, 0L);
+  return ft_check_launch("slab_sum");
+}
+
 int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t workspace_floats,
                       hipStream_t stream) {
   FtGemmTNTask t = task_in;

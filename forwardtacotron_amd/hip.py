@@ -354,7 +354,10 @@ def conv_bank_bwd_data(dy: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, C
     flag = 0
     if NT_GRADS and ws is not None and C % 4 == 0:
         wp_all, flag = bank_packs(ws, True), 1
-    _lib.call('ft_conv_bank_bwd_data', _p(dy), K * C, _p(wp_all), _p(dx), Cin, B, T, Cin, C, K, Tbuf, flag, _stream())
+    nbytes = _lib.query('ft_conv_bank_bwd_data_workspace', B, T, Cin, K)
+    ws = workspace(nbytes, dy.device) if nbytes else None
+    _lib.call('ft_conv_bank_bwd_data', _p(dy), K * C, _p(wp_all), _p(dx), Cin, B, T, Cin, C, K, Tbuf, flag,
+              _p(ws), ws.numel() if ws is not None else 0, _stream())
     return dx
 
 

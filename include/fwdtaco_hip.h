@@ -94,10 +94,14 @@ int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, l
 int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
                              int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
                              void* stream);
-/* data gradient of the whole conv bank (backward of common_layers.py:97-102) in ONE launch: the K members' products
- * are accumulated in registers into dx[B,T,Cin]; dy = [B,Tbuf,K*C] gradient of the bank buffer (Tbuf = T or T+1) */
+/* data gradient of the whole conv bank (backward of common_layers.py:97-102) in ONE GEMM launch; dy = [B,Tbuf,K*C]
+ * gradient of the bank buffer (Tbuf = T or T+1).  Long sequences: the K members' products are accumulated in registers
+ * straight into dx[B,T,Cin].  Short ones (too few output tiles to fill the chip, e.g. the prenet's B*T = 4096 rows):
+ * every member writes its own partial into `workspace` (size from the query, may be 0) and an ordered sum follows. */
+size_t ft_conv_bank_bwd_data_workspace(int B, int T, int Cin, int K);
 int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
-                          int C, int K, int Tbuf, int wp_transposed, void* stream);
+                          int C, int K, int Tbuf, int wp_transposed, void* workspace, size_t workspace_bytes,
+                          void* stream);
 /* dw[co,ci,j] = sum_{b,t'<Tvalid} dy[b,t',co] * x[b,t'+j-k/2,ci]   (torch layout [Cout][Cin][k]) */
 size_t ft_conv1d_bwd_weight_workspace(int B, int T, int Cin, int Cout, int k, int Tvalid);
 int ft_conv1d_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T, int Cin,

@@ -67,6 +67,22 @@ def test_large_gemm_split_path_is_fp32_accurate(H):
     yc = H.conv1d_fwd(dev(xc), H.conv_pack_weight(dev(wc)), relu=False)
     refc = _conv_ref(xc, wc, False)[:, :T]
     assert rel_err(yc, refc) < 2e-6
+    # weight gradients (TN form: the contraction runs over the rows of both operands; r-pair packed LDS tiles)
+    dyw = torch.randn(4096, 1024, generator=g) * torch.exp(2 * torch.randn(4096, 1, generator=g))
+    xw = torch.randn(4096, 1024, generator=g) * torch.exp(2 * torch.randn(4096, 1, generator=g))
+    dw = H.linear_bwd_weight(dev(dyw), dev(xw))
+    refw = dyw.double().t() @ xw.double()
+    scale_w = dyw.double().abs().t() @ xw.double().abs() + 1e-30
+    assert float(((dw.cpu().double() - refw).abs() / scale_w).max()) < 1e-6
+    Cin2 = 256
+    xc2 = torch.randn(B, T, Cin2, generator=g)
+    dyc = torch.randn(B, T, Cout, generator=g)
+    dwc = torch.empty(Cout, Cin2, k, device='cuda')
+    dyd = dev(dyc)
+    H.conv1d_bwd_weight_raw(dyd.data_ptr(), Cout, dev(xc2), dwc, T, T)
+    xp = torch.nn.functional.pad(xc2.double(), (0, 0, k // 2, k // 2))
+    refdw = torch.stack([torch.einsum('bto,bti->oi', dyc.double(), xp[:, j:j + T]) for j in range(k)], dim=-1)
+    assert rel_err(dwc, refdw) < 2e-6
 
 
 def test_pack_weights_one_launch(H):
@@ -190,6 +206,29 @@ def test_conv_bank_fwd(H, B, T, Cin, C, K):
         full = _conv_ref(x, w, True)
         n = full.shape[1]
         assert rel_err(y[:, :n, i * C:(i + 1) * C], full) < 3e-6, i
+
+
+@pytest.mark.parametrize('B,T,Cin,C,K', [(2, 9, 8, 8, 4), (3, 20, 12, 12, 5), (32, 128, 256, 32, 6), (4, 700, 80, 64, 8)])
+def test_conv_bank_bwd_data(H, B, T, Cin, C, K):
+    """dx of the whole bank vs autograd through the reference formulation (conv -> [:T+1 or :T] rows as the bank
+    buffer holds them).  (32,128,256,..) is prenet-shaped: few output tiles -> per-member partials + ordered sum;
+    the others take the chained launch; both through the transposed packs (NT form) and the plain ones."""
+    g = torch.Generator().manual_seed(100 + K)
+    ws = [torch.randn(C, Cin, k, generator=g) for k in range(1, K + 1)]
+    dy = torch.randn(B, T + 1, K * C, generator=g)
+    x = torch.randn(B, T, Cin, generator=g, dtype=torch.float64, requires_grad=True)
+    tot = 0
+    for i, w in enumerate(ws):
+        k = i + 1
+        full = torch.nn.functional.conv1d(x.transpose(1, 2), w.double(), padding=k // 2).transpose(1, 2)
+        n = full.shape[1]                     # T (odd k) or T+1 (even k)
+        tot = tot + (full * dy[:, :n, i * C:(i + 1) * C].double()).sum()
+    tot.backward()
+    wd = [dev(w) for w in ws]
+    wp_all = torch.cat([H.conv_pack_weight(w).reshape(-1) for w in wd])
+    dyd = dev(dy)
+    assert rel_err(H.conv_bank_bwd_data(dyd, wp_all, K, C, Cin, T, ws=wd), x.grad) < 3e-6
+    assert rel_err(H.conv_bank_bwd_data(dyd, wp_all, K, C, Cin, T), x.grad) < 3e-6
 
 
 def test_length_regulator_golden(H):
