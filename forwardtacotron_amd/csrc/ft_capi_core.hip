@@ -283,6 +283,42 @@ static FtGemmTNTask conv_bw_task(const float* dy, long lddy, const float* x, lon
   return t;
 }
 
+// weight gradients of ALL members of a conv bank in one launch (FtGemmTNTask conv-bank mode): dy [B,Tbuf,K*C] is the
+// gradient of the bank buffer, x [B,T,Cin] the bank's input, dw[i] the torch-layout [C][Cin][i+1] gradient of member i
+static FtGemmTNTask bank_bw_task(const float* dy, long lddy, const float* x, long ldx, int B, int T, int Cin, int C,
+                                 int K, int Tbuf) {
+  FtGemmTNTask t;
+  memset(&t, 0, sizeof(t));
+  t.A = dy; t.B = x;
+  t.lda = lddy; t.ldb = ldx;
+  t.M = K * C; t.N = Cin; t.R = B * Tbuf; t.taps = K;
+  FtRowMap am = {Tbuf, Tbuf, 1, Tbuf, 0, 0};
+  FtRowMap bm = {Tbuf, T, 1, T, 0, 1};
+  t.amap = am;
+  t.bmap = bm;
+  t.bankC = C;
+  t.bankTodd = T;
+  return t;
+}
+
+size_t ft_conv_bank_bwd_weight_workspace(int B, int T, int Cin, int C, int K, int Tbuf) {
+  FtGemmTNTask t = bank_bw_task(nullptr, (long)K * C, nullptr, Cin, B, T, Cin, C, K, Tbuf);
+  return ft_gemm_tn_workspace_floats(t) * sizeof(float);
+}
+
+int ft_conv_bank_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* const* dw, int B, int T,
+                            int Cin, int C, int K, int Tbuf, void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(K >= 1 && K <= FT_MAX_TASKS, "conv_bank_bwd_weight: K=%d unsupported (max %d)", K, FT_MAX_TASKS);
+  FT_REQUIRE(Tbuf == T || Tbuf == T + 1, "conv_bank_bwd_weight: Tbuf must be T or T+1");
+  FT_REQUIRE(C % 128 == 0, "conv_bank_bwd_weight: C must be a multiple of 128 (use ft_conv1d_bwd_weight per member)");
+  FtGemmTNTask t = bank_bw_task(dy, lddy, x, ldx, B, T, Cin, C, K, Tbuf);
+  for (int i = 0; i < K; ++i) {
+    FT_REQUIRE(dw[i] != nullptr, "conv_bank_bwd_weight: null dw[%d]", i);
+    t.bank_dst[i] = dw[i];
+  }
+  return ft_launch_gemm_tn(t, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 size_t ft_conv1d_bwd_weight_workspace(int B, int T, int Cin, int Cout, int k, int Tvalid) {
   FtGemmTNTask t = conv_bw_task(nullptr, Cout, nullptr, Cin, nullptr, B, T, Cin, Cout, k, Tvalid, Tvalid);
   return ft_gemm_tn_workspace_floats(t) * sizeof(float);

@@ -65,7 +65,42 @@ struct FtGemmTNTask {
   // strided batch (see FtGemmTask); dst += z0*sD0 + z1*sD1
   int nz, nz1;
   long sA0, sA1, sB0, sB1, sD0, sD1;
+  // conv-bank mode (bankC > 0): A's M columns are the K = M / bankC members of a CBHG conv bank side by side, member
+  // kk = m / bankC + 1 has kernel size kk: tap j < kk only, B row shift j - kk/2, A rows t < (kk odd ? bankTodd :
+  // amap.Tvalid); the result goes to bank_dst[kk-1] in torch layout [bankC][N][kk].  bankC % tile == 0.
+  int bankC, bankTodd;
+  float* bank_dst[FT_MAX_TASKS];
 };
+
+// Workgroup -> (M-tile, tap, split) of a TN launch.  Plain tasks: blockIdx.x = M-tile, blockIdx.z = (instance*taps +
+// tap)*S + split.  Conv-bank mode: member kk only has taps j < kk, so the grid enumerates the LIVE (member, tap, tile)
+// triples along x (kk ascending, then tap, then the member's M-tiles) and blockIdx.z = split -- no empty workgroups,
+// equal work per workgroup (the round-robin XCD assignment stays balanced), and neighbours share their dy tile.
+struct FtTnWho {
+  int mtile, zts, s, kk;      // zts = instance*taps + tap ; kk = member (bank mode) or 0
+};
+__device__ __forceinline__ FtTnWho ft_tn_who(const FtGemmTNTask& T, int S, int BM) {
+  FtTnWho w;
+  if (T.bankC > 0) {
+    const int tpm = T.bankC / BM;                 // M-tiles per member
+    const int q = blockIdx.x / tpm, sub = blockIdx.x - q * tpm;
+    int kk = 1, first = 0;                        // first = kk(kk-1)/2 = index of (kk, tap 0)
+    while (first + kk <= q) {
+      first += kk;
+      ++kk;
+    }
+    w.kk = kk;
+    w.zts = q - first;
+    w.mtile = (kk - 1) * tpm + sub;
+    w.s = blockIdx.z;
+  } else {
+    w.kk = 0;
+    w.mtile = blockIdx.x;
+    w.zts = blockIdx.z / S;
+    w.s = blockIdx.z - w.zts * S;
+  }
+  return w;
+}
 
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream);
 // fp32 on the bf16 matrix pipe (exact 3-way operand split, ft_gemm_b3.hip); NT + FAST launches, FT_GEMM_B3=0 disables

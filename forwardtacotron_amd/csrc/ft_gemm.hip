@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
   constexpr int STAGE = BK * LDA + BK * LDB;    // two LDS stages, one barrier per K-stage (see rows kernel)
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  // blockIdx.z = ((instance * taps) + tap) * S + split
-  const int zts = blockIdx.z / S, s = blockIdx.z - zts * S;
+  const FtTnWho who = ft_tn_who(T, S, BM);
+  const int m0 = who.mtile * BM, n0 = blockIdx.y * BN;
+  const int zts = who.zts, s = who.s;
   const int zi = zts / T.taps, tap = zts - zi * T.taps;
   const float* TA = T.A;
   const float* TB = T.B;
@@ -336,14 +336,19 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
   const int tid = threadIdx.x;
   const int aq = tid % AQ, ar = tid / AQ;
   const int bq = tid % BQ, br = tid / BQ;
-  const int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
+  int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
   const int ashift = T.amap.shift0 + tap * T.amap.shift_step;
+  int aTvalid = T.amap.Tvalid;
+  if (who.kk > 0) {                           // conv-bank mode: this tile's member decides shift / valid rows
+    bshift = tap - who.kk / 2;
+    if (who.kk & 1) aTvalid = T.bankTodd;
+  }
 
   // task fields as locals (see the rows kernel) and (item, t) of every staged row tracked incrementally: stages are
   // requested in strictly increasing order, BK rows apart, so the per-row integer division happens once
   const int tM = T.M, tN = T.N;
   const long lda = T.lda, ldb = T.ldb;
-  const int aTlog = T.amap.Tlog, aTvalid = T.amap.Tvalid, bTlog = T.bmap.Tlog, bTvalid = T.bmap.Tvalid;
+  const int aTlog = T.amap.Tlog, bTlog = T.bmap.Tlog, bTvalid = T.bmap.Tvalid;
   const long abst = T.amap.bstride, atst = T.amap.tstride, bbst = T.bmap.bstride, btst = T.bmap.tstride;
   const bool avec = T.a_vec, bvec = T.b_vec;
   const int am = m0 + 4 * aq, bn = n0 + 4 * bq;
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256) void ft_gemm_tn_kernel(FtGemmTNTask T, float* 
       __syncthreads();
     }
   }
-  float* out = slab + (long)blockIdx.z * T.M * T.N;
+  float* out = slab + ((long)zts * S + s) * T.M * T.N;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -466,6 +471,24 @@ __global__ void ft_splitk_reduce_kernel(const float* slab, float* dst, int M, in
   *d = accumulate ? *d + acc : acc;
 }
 
+// conv-bank mode: dst_kk[(co*N + n)*kk + j] = sum_s slab[j*S + s][(kk-1)*C + co][n], one thread per (m, n)
+struct BankDst {
+  float* p[FT_MAX_TASKS];
+};
+__global__ void ft_bank_wgrad_reduce_kernel(const float* __restrict__ slab, BankDst dst, int M, int N, int C, int S) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
+  const int member = m / C, kk = member + 1, co = m - member * C;
+  float* d = dst.p[member] + ((long)co * N + n) * kk;
+  for (int j = 0; j < kk; ++j) {
+    const float* p = slab + ((long)j * S) * M * N + idx;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += p[(long)s * M * N];
+    d[j] = acc;
+  }
+}
+
 struct TNPlan {
   int tm, tn, S, rows_per_split;
 };
@@ -494,6 +517,18 @@ TNPlan plan_tn(const FtGemmTNTask& t, bool b3_ok) {
   int bm = 64 * p.tm;
   long tiles = (long)ft_cdiv(t.M, bm) * ft_cdiv(t.N, bm) * t.taps * nz;
   long want = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+  if (t.bankC > 0) {
+    // conv-bank mode: member kk only has taps j < kk, i.e. (K+1)/(2K) of the grid does work; aim for ~4 waves of
+    // workgroups so that the last, partial wave costs little
+    const long K = t.taps;
+    const long live = tiles * (K + 1) / (2 * K);
+    want = (2048 + live - 1) / (live > 0 ? live : 1);
+  }
+  static const long force_s = [] {             // FT_TN_FORCE_S=<n>: tuning aid (scratch/tn_split_lab.py)
+    const char* e = getenv("FT_TN_FORCE_S");
+    return e ? atol(e) : 0L;
+  }();
+  if (force_s > 0) want = force_s;
   long S = want < maxs ? want : maxs;
   if (S > 65535 / ((long)t.taps * nz)) S = 65535 / ((long)t.taps * nz);
   if (S < 1) S = 1;
@@ -662,6 +697,13 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
              workspace_floats, need);
   const int bm = 64 * p.tm;
   dim3 grid(ft_cdiv(t.M, bm), ft_cdiv(t.N, bm), p.S * t.taps * t.nz);
+  if (t.bankC > 0) {
+    FT_REQUIRE(t.bankC % bm == 0 && t.M % t.bankC == 0 && t.M / t.bankC <= FT_MAX_TASKS && t.taps == t.M / t.bankC &&
+                   t.nz == 1 && !t.accumulate,
+               "gemm_tn: bad conv-bank task");
+    const int K = t.taps;
+    grid = dim3((t.bankC / bm) * (K * (K + 1) / 2), ft_cdiv(t.N, bm), p.S);      // live (member, tap, tile) triples
+  }
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_tn: grid too large");
   GemmLog log;
   log.begin(stream);
@@ -680,6 +722,19 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   int rc = ft_check_launch("gemm_tn");
   if (rc) return rc;
   long total = (long)t.nz * t.taps * t.M * t.N;
+  if (t.bankC > 0) {
+    BankDst bd;
+    for (int i = 0; i < FT_MAX_TASKS; ++i) bd.p[i] = t.bank_dst[i];
+    hipLaunchKernelGGL(ft_bank_wgrad_reduce_kernel, dim3(ft_cdiv((long)t.M * t.N, 256)), dim3(256), 0, stream, workspace,
+                       bd, t.M, t.N, t.bankC, p.S);
+    if (GemmLog::on()) {
+      char var[32];
+      snprintf(var, sizeof(var), "%d/S%d", 64 * p.tm, p.S);
+      const int K = t.M / t.bankC;
+      log.end("tnbank", t.M, t.N, t.R, t.taps, t.nz, var, 2.0 * t.bankC * t.N * t.R * (K * (K + 1) / 2));
+    }
+    return ft_check_launch("bank_wgrad_reduce");
+  }
   hipLaunchKernelGGL(ft_splitk_reduce_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, stream, workspace, t.dst,
                      t.M, t.N, t.taps, p.S, t.ldm, t.ldn, t.ldj, t.accumulate, t.nz, t.nz1, t.sD0, t.sD1);
   if (GemmLog::on()) {

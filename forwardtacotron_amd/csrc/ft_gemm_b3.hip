@@ -257,8 +257,9 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
   unsigned* As = smem;
   unsigned* Bs = smem + 3 * PLA;
 
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int zts = blockIdx.z / S, s = blockIdx.z - zts * S;
+  const FtTnWho who = ft_tn_who(T, S, BM);
+  const int m0 = who.mtile * BM, n0 = blockIdx.y * BN;
+  const int zts = who.zts, s = who.s;
   const int zi = zts / T.taps, tap = zts - zi * T.taps;
   const float* TA = T.A;
   const float* TB = T.B;
@@ -272,10 +273,15 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
   const int tid = threadIdx.x;
   const int tM = T.M, tN = T.N;
   const long lda = T.lda, ldb = T.ldb;
-  const int aTlog = T.amap.Tlog, aTvalid = T.amap.Tvalid, bTlog = T.bmap.Tlog, bTvalid = T.bmap.Tvalid;
+  const int aTlog = T.amap.Tlog, bTlog = T.bmap.Tlog, bTvalid = T.bmap.Tvalid;
   const long abst = T.amap.bstride, atst = T.amap.tstride, bbst = T.bmap.bstride, btst = T.bmap.tstride;
   const int ashift = T.amap.shift0 + tap * T.amap.shift_step;
-  const int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
+  int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
+  int aTvalid = T.amap.Tvalid;
+  if (who.kk > 0) {                           // conv-bank mode (FtGemmTNTask): member of this tile
+    bshift = tap - who.kk / 2;
+    if (who.kk & 1) aTvalid = T.bankTodd;
+  }
 
   const int amq = tid % MQ, aq0 = tid / MQ;          // this thread's column quad / first pair-row, per operand
   const int bmq = tid % NQ, bq0 = tid / NQ;
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
       }
     }
   }
-  float* out = slab + (long)blockIdx.z * tM * tN;
+  float* out = slab + ((long)zts * S + s) * tM * tN;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll

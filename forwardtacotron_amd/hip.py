@@ -361,6 +361,22 @@ def conv_bank_bwd_data(dy: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, C
     return dx
 
 
+def conv_bank_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dws: Sequence[torch.Tensor], C: int) -> None:
+    """dy [B,Tbuf,K*C] gradient of the bank buffer, x [B,T,Cin]; overwrites dws[i] ([C,Cin,i+1]) for all K members
+    with one GEMM launch (C % 128 == 0)."""
+    _chk(dy, 'dy'); _chk(x, 'x')
+    B, T, Cin = x.shape
+    Tbuf, K = dy.shape[1], len(dws)
+    for i, d in enumerate(dws):
+        _chk(d, 'dw')
+        if tuple(d.shape) != (C, Cin, i + 1):
+            raise _lib.FtError(f'conv_bank_bwd_weight: dw[{i}] has shape {tuple(d.shape)}')
+    nbytes = _lib.query('ft_conv_bank_bwd_weight_workspace', B, T, Cin, C, K, Tbuf)
+    ws = workspace(nbytes, x.device)
+    _lib.call('ft_conv_bank_bwd_weight', _p(dy), K * C, _p(x), Cin, _ptr_array(dws), B, T, Cin, C, K, Tbuf, _p(ws),
+              ws.numel(), _stream())
+
+
 def conv1d_bwd_weight_raw(dy_ptr: int, lddy: int, x: torch.Tensor, dw: torch.Tensor, Tbuf: int, Tvalid: int) -> None:
     B, T, Cin = x.shape
     Cout, _, k = dw.shape

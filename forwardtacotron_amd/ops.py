@@ -88,6 +88,29 @@ def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
     return None
 
 
+def _emit_multi(ws, compute, deps=()):
+    """_emit for several parameters whose gradients one launch produces together: compute(outs)."""
+    ents = [_sink_view(w) for w in ws]
+    if any(e is None for e in ents):
+        outs = [torch.empty_like(w) for w in ws]
+        compute(outs)
+        return outs
+    side = _SINK.stream
+    views = [e[1] for e in ents]
+    if side is None:
+        compute(views)
+    else:
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        for t in deps:
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            compute(views)
+    for e in ents:
+        _sink_done(e[0])
+    return [None] * len(ws)
+
+
 def _emit_copy(w: torch.Tensor, value: torch.Tensor):
     """Small vector gradients that a fused kernel already produced in `value`."""
     ent = _sink_view(w)
@@ -242,16 +265,16 @@ class ConvBankFn(Function):
         dz = H.maxpool2_bwd(_c(dout), z)
         dy, dgamma, dbeta = H.bn_bwd(dz, ybank, gamma, mean, rstd, group=C, relu=True)
         dx = H.conv_bank_bwd_data(dy, wp_all, K, C, Cin, T, ws=ws) if ctx.needs_input_grad[0] else None
-        dws = []
-        off = 0
-        for i in range(K):
-            k = i + 1
-            n = k * C * Cin
-            Tvalid = T + (1 if k % 2 == 0 else 0)
-            dptr = dy.data_ptr() + i * C * _F4
-            dws.append(_emit(ws[i], lambda out, dptr=dptr, Tvalid=Tvalid: H.conv1d_bwd_weight_raw(
-                dptr, K * C, x, out, T + 1, Tvalid), (dy, x)))
-            off += n
+        if C % 128 == 0:        # all members' weight gradients in one launch
+            dws = _emit_multi(ws, lambda outs: H.conv_bank_bwd_weight(dy, x, outs, C), (dy, x))
+        else:
+            dws = []
+            for i in range(K):
+                k = i + 1
+                Tvalid = T + (1 if k % 2 == 0 else 0)
+                dptr = dy.data_ptr() + i * C * _F4
+                dws.append(_emit(ws[i], lambda out, dptr=dptr, Tvalid=Tvalid: H.conv1d_bwd_weight_raw(
+                    dptr, K * C, x, out, T + 1, Tvalid), (dy, x)))
         dgs = [_emit_copy(gs[i], dgamma[i * C:(i + 1) * C]) for i in range(K)]
         dbs = [_emit_copy(bs[i], dbeta[i * C:(i + 1) * C]) for i in range(K)]
         return (dx, None, None, None, None, None, *dws, *dgs, *dbs)

@@ -102,6 +102,12 @@ size_t ft_conv_bank_bwd_data_workspace(int B, int T, int Cin, int K);
 int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float* dx, long lddx, int B, int T, int Cin,
                           int C, int K, int Tbuf, int wp_transposed, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* weight gradients of ALL K members of a conv bank in one GEMM launch + one ordered reduction: dy [B,Tbuf,K*C] =
+ * gradient of the bank buffer, x [B,T,Cin] = the bank's input, dw = HOST array of K device pointers, dw[i] =
+ * torch-layout [C][Cin][i+1] gradient of member i (kernel size i+1).  C % 128 == 0. */
+size_t ft_conv_bank_bwd_weight_workspace(int B, int T, int Cin, int C, int K, int Tbuf);
+int ft_conv_bank_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* const* dw, int B, int T,
+                            int Cin, int C, int K, int Tbuf, void* workspace, size_t workspace_bytes, void* stream);
 /* dw[co,ci,j] = sum_{b,t'<Tvalid} dy[b,t',co] * x[b,t'+j-k/2,ci]   (torch layout [Cout][Cin][k]) */
 size_t ft_conv1d_bwd_weight_workspace(int B, int T, int Cin, int Cout, int k, int Tvalid);
 int ft_conv1d_bwd_weight(const float* dy, long lddy, const float* x, long ldx, float* dw, int B, int T, int Cin,

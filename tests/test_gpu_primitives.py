@@ -231,6 +231,31 @@ def test_conv_bank_bwd_data(H, B, T, Cin, C, K):
     assert rel_err(H.conv_bank_bwd_data(dyd, wp_all, K, C, Cin, T), x.grad) < 3e-6
 
 
+@pytest.mark.parametrize('B,T,Cin,C,K', [(2, 40, 16, 128, 3), (8, 128, 256, 256, 5), (4, 333, 80, 128, 8)])
+def test_conv_bank_bwd_weight_one_launch(H, B, T, Cin, C, K):
+    """All members' weight gradients from one launch (conv-bank mode of the TN GEMM) vs float64 autograd through
+    the reference formulation; also equal (to rounding) to the per-member launches."""
+    g = torch.Generator().manual_seed(200 + K)
+    x = torch.randn(B, T, Cin, generator=g)
+    dy = torch.randn(B, T + 1, K * C, generator=g)
+    ws = [torch.zeros(C, Cin, k, dtype=torch.float64, requires_grad=True) for k in range(1, K + 1)]
+    tot = 0
+    for i, w in enumerate(ws):
+        k = i + 1
+        full = torch.nn.functional.conv1d(x.double().transpose(1, 2), w, padding=k // 2).transpose(1, 2)
+        tot = tot + (full * dy[:, :full.shape[1], i * C:(i + 1) * C].double()).sum()
+    tot.backward()
+    xd, dyd = dev(x), dev(dy)
+    dws = [torch.full((C, Cin, k), float('nan'), device='cuda') for k in range(1, K + 1)]
+    H.conv_bank_bwd_weight(dyd, xd, dws, C)
+    for i, w in enumerate(ws):
+        k = i + 1
+        assert rel_err(dws[i], w.grad) < 3e-6, i
+        one = torch.empty(C, Cin, k, device='cuda')
+        H.conv1d_bwd_weight_raw(dyd.data_ptr() + i * C * 4, K * C, xd, one, T + 1, T + (1 if k % 2 == 0 else 0))
+        assert rel_err(dws[i], one) < 2e-6, i
+
+
 def test_length_regulator_golden(H):
     L = load_npz('layers.npz')
     x = torch.from_numpy(L['lr/x']); dur = torch.from_numpy(L['lr/dur_in'].copy())
