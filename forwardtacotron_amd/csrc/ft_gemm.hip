@@ -517,6 +517,10 @@ TNPlan plan_tn(const FtGemmTNTask& t, bool b3_ok) {
   int bm = 64 * p.tm;
   long tiles = (long)ft_cdiv(t.M, bm) * ft_cdiv(t.N, bm) * t.taps * nz;
   long want = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+  // the split-path kernel holds exactly 2 workgroups per CU (53 KB LDS, 220 VGPRs) = 512 slots: a grid slightly above
+  // one full wave pays a second, nearly empty one (576 workgroups ran at 94 TF, 512 at 134) -> round DOWN there
+  const bool split_path = b3_ok && tn_b3_mode() >= 1 && p.tm == 2;
+  if (split_path && tiles < 512) want = 512 / tiles;
   if (t.bankC > 0) {
     // conv-bank mode: member kk only has taps j < kk, i.e. (K+1)/(2K) of the grid does work; aim for ~4 waves of
     // workgroups so that the last, partial wave costs little

@@ -325,6 +325,9 @@ class ForwardTacotron(nn.Module):
         pitch = batch['pitch']               # [B,Tx]  (the reference unsqueezes to [B,1,Tx] for its Conv1d)
         energy = batch['energy']
 
+        # token-side row count (incl. the conv bank's extra row): trainer.TrainStep keeps weight gradients of
+        # operands this short on the main stream (ops.GradSink.inline_rows)
+        self.wgrad_inline_rows = x.shape[0] * (x.shape[1] + 1)
         if self.training:
             self.step += 1
             self._bump_batchnorm_counters()

@@ -171,6 +171,9 @@ class MultiForwardTacotron(nn.Module):
         pitch_cond = batch['pitch_cond']
         energy = batch['energy']
         self._require_device(x)
+        # token-side row count (incl. the conv bank's extra row): trainer.TrainStep keeps weight gradients of
+        # operands this short on the main stream (ops.GradSink.inline_rows)
+        self.wgrad_inline_rows = x.shape[0] * (x.shape[1] + 1)
         if self.training:
             self.step += 1
             self._bump_batchnorm_counters()

@@ -34,6 +34,13 @@ class GradSink:
         self.written = set()
         self.stream = stream            # side stream for weight-gradient GEMMs (None: current stream)
         self.on_write = on_write        # callback(index) -> lets the bucketed all-reduce count arrivals
+        # weight-gradient GEMMs whose operands have at most this many rows stay on the CURRENT stream (0: none do).
+        # ForwardTacotron sets it to its token-side row count: those gradients (prenet, predictors) only become
+        # computable at the very end of the backward, right after the first LSTM's four big weight gradients landed
+        # on the side stream -- left there they queue behind them while the main stream has nothing left to do
+        # (1.9 ms of a 28.4 ms step); on the main stream the two tails overlap.  FastPitch, whose whole token side
+        # is launch-bound, is faster with everything on the side stream and leaves it at 0.
+        self.inline_rows = 0
 
     def begin_step(self):
         self.written.clear()
@@ -75,6 +82,8 @@ def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
         return out
     idx, view = ent
     side = _SINK.stream if heavy else None
+    if side is not None and deps and deps[0].numel() // deps[0].shape[-1] <= _SINK.inline_rows:
+        side = None                     # short (token-side) operands: see GradSink.inline_rows
     if side is None:
         compute(view)
     else:
@@ -96,6 +105,8 @@ def _emit_multi(ws, compute, deps=()):
         compute(outs)
         return outs
     side = _SINK.stream
+    if side is not None and deps and deps[0].numel() // deps[0].shape[-1] <= _SINK.inline_rows:
+        side = None
     views = [e[1] for e in ents]
     if side is None:
         compute(views)

@@ -116,6 +116,7 @@ class TrainStep:
             self.flat.zero_grad()
             self.reducer.start()
             self.sink.begin_step()
+            self.sink.inline_rows = int(getattr(model, 'wgrad_inline_rows', 0))
             ops.set_grad_sink(self.sink)
             try:
                 L['loss'].backward()
