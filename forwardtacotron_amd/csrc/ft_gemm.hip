@@ -465,28 +465,44 @@ __global__ void ft_splitk_reduce_kernel(const float* slab, float* dst, int M, in
   int zi = zt / taps, tap = zt - zi * taps;
   int m = (int)(mn / N), n = (int)(mn - (long)m * N);
   const float* p = slab + ((long)zt * S) * M * N + mn;
+  const long plane = (long)M * N;
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += p[(long)s * M * N];
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {                     // four loads in flight, summed in slab order
+    const float a0 = p[(long)s * plane], a1 = p[(long)(s + 1) * plane], a2 = p[(long)(s + 2) * plane],
+                a3 = p[(long)(s + 3) * plane];
+    acc = (((acc + a0) + a1) + a2) + a3;
+  }
+  for (; s < S; ++s) acc += p[(long)s * plane];
   float* d = dst + (zi / nz1) * sD0 + (zi % nz1) * sD1 + m * ldm + n * ldn + tap * ldj;
   *d = accumulate ? *d + acc : acc;
 }
 
-// conv-bank mode: dst_kk[(co*N + n)*kk + j] = sum_s slab[j*S + s][(kk-1)*C + co][n], one thread per (m, n)
+// conv-bank mode: dst_kk[(co*N + n)*kk + j] = sum_s slab[j*S + s][(kk-1)*C + co][n], one thread per (m, n, tap j)
 struct BankDst {
   float* p[FT_MAX_TASKS];
 };
 __global__ void ft_bank_wgrad_reduce_kernel(const float* __restrict__ slab, BankDst dst, int M, int N, int C, int S) {
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;                        // tap
   if (idx >= (long)M * N) return;
   const int m = (int)(idx / N), n = (int)(idx - (long)m * N);
   const int member = m / C, kk = member + 1, co = m - member * C;
-  float* d = dst.p[member] + ((long)co * N + n) * kk;
-  for (int j = 0; j < kk; ++j) {
-    const float* p = slab + ((long)j * S) * M * N + idx;
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += p[(long)s * M * N];
-    d[j] = acc;
+  if (j >= kk) return;
+  const long plane = (long)M * N;
+  const float* p = slab + ((long)j * S) * plane + idx;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;    // four loads in flight; summed in slab order below
+  int s = 0;
+  float acc = 0.f;
+  for (; s + 4 <= S; s += 4) {
+    a0 = p[(long)s * plane];
+    a1 = p[(long)(s + 1) * plane];
+    a2 = p[(long)(s + 2) * plane];
+    a3 = p[(long)(s + 3) * plane];
+    acc = (((acc + a0) + a1) + a2) + a3;
   }
+  for (; s < S; ++s) acc += p[(long)s * plane];
+  dst.p[member][((long)co * N + n) * kk + j] = acc;
 }
 
 struct TNPlan {
@@ -729,8 +745,8 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   if (t.bankC > 0) {
     BankDst bd;
     for (int i = 0; i < FT_MAX_TASKS; ++i) bd.p[i] = t.bank_dst[i];
-    hipLaunchKernelGGL(ft_bank_wgrad_reduce_kernel, dim3(ft_cdiv((long)t.M * t.N, 256)), dim3(256), 0, stream, workspace,
-                       bd, t.M, t.N, t.bankC, p.S);
+    hipLaunchKernelGGL(ft_bank_wgrad_reduce_kernel, dim3(ft_cdiv((long)t.M * t.N, 256), t.taps), dim3(256), 0, stream,
+                       workspace, bd, t.M, t.N, t.bankC, p.S);
     if (GemmLog::on()) {
       char var[32];
       snprintf(var, sizeof(var), "%d/S%d", 64 * p.tm, p.S);
