@@ -525,6 +525,193 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward, reduce-scatter form (bf16-split only): the same workgroup = 16 batch rows x 16 hidden units, but the
+// recurrent product is formed on the PRODUCER side.  The all-gather form above makes every workgroup pull all G*H
+// d(gates) of its 16 rows each step (LSTM-512: 128 KB per workgroup per step through one L1, plus the 3-way split of
+// 32 K values) to contract them with its W_hh columns.  Here a workgroup contracts only ITS OWN 16 units' d(gates)
+// ([16 rows] x [16 G k's], padded to 64) with its W_hh ROWS -- resident in registers, same 128 KB -- which yields a
+// partial of ALL H outputs, and hands tile c' (16 units) of it to workgroup c':
+//   exchange layout  xb[parity][group][consumer c'][producer p][unit 16][row 16]   (1 KB blocks; an MFMA result lane
+//                    holds 4 rows of one unit = one 16-B write-through store per tile)
+//   consumer: after the arrival wait its 256 cell threads each read ONE float per producer (p-th block + tid,
+//             fully coalesced) and add them in producer order -> d(h) of (row, unit); cell math; the new d(gates)
+//             go to LDS, every wave splits them (1 K values, not 32 K) and multiplies its output tiles.
+// Per step a workgroup reads nchunks KB (32) instead of G*H*64 B (128 KB) and splits 1/32 of the values; the cross-
+// workgroup hand-off (stores -> vmcnt(0) -> per-wave arrival -> poll -> loads) is the same as above.
+// ---------------------------------------------------------------------------------------------------
+template <int G, int NW, int NT>
+__global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Geom geo, float* xb, unsigned* cnt,
+                                                                unsigned* err, unsigned xb_bytes) {
+  constexpr int ALD = 68;                             // LDS row stride of the local d(gates) tile [16][64]
+  constexpr int PC = NW * NT;                         // chunks per group = H / 16 (checked by the host)
+  __shared__ __attribute__((aligned(16))) float adg[16 * ALD];
+  __shared__ int s_ok;
+  int d, bgp, chunk, grp;
+  if (!decode(geo, d, bgp, chunk, grp)) return;
+  const int u0 = chunk * 16, b0 = bgp * MB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = lane >> 4, l15 = lane & 15;
+  const int H = a.H, T = a.T, K = G * H, P = geo.nchunks;
+  const long ldg = (long)a.ND * K;
+  const long ldo = (long)a.ND * H;
+  const long grp_floats = (long)P * P * 256;
+  const long par_floats = (long)2 * geo.nbg * grp_floats;
+  const long base_floats = (long)grp * grp_floats;
+  unsigned* mycnt = cnt + (long)grp * NSH * CSTRIDE;
+  const int nprod = NW * P;                           // every wave signals its own stores
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xb_bytes, 0x00020000);
+
+  // ---- resident W_hh rows of this workgroup's units, as B fragments: tile nt = consumer chunk wave*NT + nt, column
+  //      l15 = output unit n; local k = g*16 + j  <->  W_hh[g*H + u0 + j][n] = whhT[n][g*H + u0 + j]
+  bf16x8 bw[NT][2][3];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (wave * NT + nt) * 16 + l15;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const int g = 2 * blk + (q >> 1), j0 = 8 * (q & 1);
+      const bool in = g < G && n < H;
+      const float* p = a.whhT[d] + (in ? (long)n * K + (long)g * H + u0 + j0 : 0);
+      const float4 z = make_float4(0, 0, 0, 0);
+      split8(in ? *reinterpret_cast<const float4*>(p) : z, in ? *reinterpret_cast<const float4*>(p + 4) : z,
+             bw[nt][blk][0], bw[nt][blk][1], bw[nt][blk][2]);
+    }
+  }
+  for (int i = tid; i < 16 * ALD; i += NW * 64) adg[i] = 0.f;      // (GRU: k 48..63 stay zero)
+
+  // ---- cell threads (first 256): thread = (unit cj, row ci), the order of an exchange block
+  const int cj = tid >> 4, ci = tid & 15;
+  const int cb = b0 + ci, cun = u0 + cj;
+  const bool sthr = tid < 256;
+  const bool cthr = sthr && cb < a.B;
+  const int L = cthr ? clamp_len(a.lens, cb, T) : 0;
+  float carry = 0.f;
+
+  float gv[4] = {0.f, 0.f, 0.f, 0.f}, dov = 0.f, cc = 0.f, prev = 0.f;
+  auto request = [&](int sn, float (&rgv)[4], float& rdo, float& rcc, float& rprev) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rgv[g] = 0.f;
+    rdo = 0.f; rcc = 0.f; rprev = 0.f;
+    if (cthr && sn < L) {
+      const int ct = d == 0 ? L - 1 - sn : sn;
+      const int tprev = d == 0 ? ct - 1 : ct + 1;
+      const bool has_prev = tprev >= 0 && tprev < L;
+      const long o = ((long)ct * a.B + cb) * ldo + (long)d * H + cun;
+      const long op = ((long)tprev * a.B + cb) * ldo + (long)d * H + cun;
+      const float* gs = a.gates + (((long)ct * a.B + cb) * a.ND + d) * 4 * H + cun;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rgv[g] = gs[(long)g * H];
+      rdo = a.dout[o];
+      if (G == 3) {
+        rprev = has_prev ? a.out[op] : 0.f;
+      } else {
+        rcc = a.cst[o];
+        rprev = has_prev ? a.cst[op] : 0.f;
+      }
+    }
+  };
+  request(0, gv, dov, cc, prev);
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const bool cact = cthr && s < L;
+    const int ct = d == 0 ? L - 1 - s : s;
+    float rec = 0.f;
+    if (s > 0) {
+      if (wave == 0) {
+        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
+        if (lane == 0) s_ok = ok;
+      }
+      __syncthreads();
+      if (!s_ok) {
+        if (tid == 0) atomicExch(err, 1u);
+        return;
+      }
+      if (sthr) {       // the P partials of (row ci, unit cj), summed in producer order
+        const long rbase = (long)((s - 1) & 1) * par_floats + base_floats + (long)chunk * P * 256 + tid;
+        float v[PC];                                   // all loads in flight at once: one round trip
+#pragma unroll
+        for (int i = 0; i < PC; ++i)
+          v[i] = __uint_as_float(
+              __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((rbase + (long)i * 256) * 4), 0, 16));
+#pragma unroll
+        for (int i = 0; i < PC; ++i) rec += v[i];
+      }
+    }
+    float ngv[4], ndo, ncc, nprev;
+    request(s + 1, ngv, ndo, ncc, nprev);
+
+    float dgx[4] = {0.f, 0.f, 0.f, 0.f}, dgh2 = 0.f;
+    if (cact) {
+      if (G == 3) {
+        const float dh = dov + rec + carry;
+        const float r = gv[0], z = gv[1], n = gv[2], hn = gv[3];
+        const float dz = dh * (prev - n) * z * (1.f - z);
+        const float dn = dh * (1.f - z) * (1.f - n * n);
+        const float dr = dn * hn * r * (1.f - r);
+        dgx[0] = dr; dgx[1] = dz; dgx[2] = dn;
+        dgh2 = dn * r;
+        carry = dh * z;
+      } else {
+        const float dh = dov + rec;
+        const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
+        const float tc = ft_tanh(cc);
+        const float dc = dh * og * (1.f - tc * tc) + carry;
+        dgx[0] = dc * gg * ig * (1.f - ig);
+        dgx[1] = dc * prev * fg * (1.f - fg);
+        dgx[2] = dc * ig * (1.f - gg * gg);
+        dgx[G - 1] = dh * tc * og * (1.f - og);
+        dgh2 = dgx[2];
+        carry = dc * fg;
+      }
+    }
+    if (sthr) {         // a finished item's rows are published as zeros
+#pragma unroll
+      for (int g = 0; g < G; ++g) adg[ci * ALD + g * 16 + cj] = (G == 3 && g == 2) ? dgh2 : dgx[g];
+    }
+    __syncthreads();
+
+    if (s + 1 < T) {    // (the last step's product has no reader)
+      bf16x8 a3[2][3];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const float* ap = adg + l15 * ALD + 32 * blk + 8 * q;
+        split8(*reinterpret_cast<const float4*>(ap), *reinterpret_cast<const float4*>(ap + 4), a3[blk][0], a3[blk][1],
+               a3[blk][2]);
+      }
+      const long wbase = (long)(s & 1) * par_floats + base_floats + (long)chunk * 256 + l15 * 16 + 4 * q;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mfma6(a3[0], bw[nt][0], acc);
+        mfma6(a3[1], bw[nt][1], acc);
+        const int cons = wave * NT + nt;
+        if (cons < P) {
+          u32x4 v = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)((wbase + (long)cons * P * 256) * 4), 0, 16);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_fetch_add(mycnt + ((NW * chunk + wave) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (cact) {
+      float* dx = a.dxp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
+#pragma unroll
+      for (int g = 0; g < G; ++g) dx[(long)g * H] = dgx[g];
+      if (G == 3) {
+        float* dhh = a.dhp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
+        dhh[0] = dgx[0]; dhh[H] = dgx[1]; dhh[2 * H] = dgh2;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gv[g] = ngv[g];
+    dov = ndo; cc = ncc; prev = nprev;
+  }
+}
+
 int g_persistent = -1;      // -1: take FT_RNN_PERSISTENT from the environment
 bool persistent_enabled() {
   if (g_persistent < 0) {
@@ -563,6 +750,18 @@ PersistWs carve_ws(void* ws, int ngrp, int K) {
   p.err = (unsigned*)ws;
   p.cnt = p.err + CSTRIDE;
   p.xb_bytes = (size_t)2 * ngrp * (K / 4) * MB * 4 * sizeof(float);
+  p.xb = (float*)((char*)ws + cnt_bytes);
+  p.total_bytes = cnt_bytes + p.xb_bytes;
+  return p;
+}
+
+// reduce-scatter backward: xb[parity][group][consumer][producer][256]
+PersistWs carve_ws_rs(void* ws, int ngrp, int nchunks) {
+  PersistWs p;
+  size_t cnt_bytes = (size_t)(1 + ngrp * NSH) * CSTRIDE * sizeof(unsigned);
+  p.err = (unsigned*)ws;
+  p.cnt = p.err + CSTRIDE;
+  p.xb_bytes = (size_t)2 * ngrp * nchunks * nchunks * 256 * sizeof(float);
   p.xb = (float*)((char*)ws + cnt_bytes);
   p.total_bytes = cnt_bytes + p.xb_bytes;
   return p;
@@ -619,6 +818,37 @@ int launch_bwd_persist(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p,
   return ft_check_launch("rnn_bwd_persistent");
 }
 
+template <int G, int NW, int NT>
+int launch_bwd_rs(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
+  if (!grid_fits(ft_rnn_bwd_rs_kernel<G, NW, NT>, NW * 64, grid)) return -1;
+  // only the status word and the arrival counters need zeroing: every exchange block is written before it is read
+  (void)hipMemsetAsync(p.err, 0, (size_t)((char*)p.xb - (char*)p.err), stream);
+  hipLaunchKernelGGL((ft_rnn_bwd_rs_kernel<G, NW, NT>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt, p.err,
+                     (unsigned)p.xb_bytes);
+  return ft_check_launch("rnn_bwd_persistent_rs");
+}
+
+// reduce-scatter form: H/16 output tiles over NW waves, NT tiles each; -1 if it does not apply
+template <int G>
+int bwd_persistent_rs(RnnBwdArgs a, const Geom& geo, void* ws, size_t ws_bytes, int grid, hipStream_t stream) {
+  const int tiles = a.H / 16;
+  if (!env_int("FT_RNN_BWD_RS", 1) || !env_int("FT_RNN_B3", 1) || !geo.sig_per_wave) return -1;
+  PersistWs p = carve_ws_rs(ws, 2 * geo.nbg, geo.nchunks);
+  if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
+  // measured (scratch/rnn_step_us.py, B = 32, us/step, all-gather -> reduce-scatter): LSTM H=512 5.26 -> 4.67;
+  // GRU H=256 3.15 -> 3.60, H=128 2.87 -> 2.95, H=64 2.70 -> 2.73: the form pays once the gathered operand is large
+  // (G*H >= 1024 values per row); FT_RNN_BWD_RS=2 forces it wherever it applies
+  const bool force = env_int("FT_RNN_BWD_RS", 1) == 2;
+  if (!force && G * a.H < 1024) return -1;
+  switch (tiles) {
+    case 4: return launch_bwd_rs<G, 4, 1>(a, geo, p, grid, stream);
+    case 8: return launch_bwd_rs<G, 8, 1>(a, geo, p, grid, stream);
+    case 16: return launch_bwd_rs<G, 8, 2>(a, geo, p, grid, stream);
+    case 32: return launch_bwd_rs<G, 8, 4>(a, geo, p, grid, stream);
+    default: return -1;
+  }
+}
+
 template <int G>
 int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {
   if (!persistent_enabled() || !ws || a.T < 2) return -1;
@@ -636,10 +866,14 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.total = 2 * geo.nbg * geo.nchunks;
   geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
   geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
-  PersistWs p = carve_ws(ws, 2 * geo.nbg, K);
-  if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   const int grid = 8 * ft_cdiv(geo.total, 8);
   a.s = 0;
+  {
+    const int rc = bwd_persistent_rs<G>(a, geo, ws, ws_bytes, grid, stream);
+    if (rc != -1) return rc;
+  }
+  PersistWs p = carve_ws(ws, 2 * geo.nbg, K);
+  if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   if (K % 32 == 0 && ft_cdiv(K / 32, NW) <= GW / 2 && env_int("FT_RNN_B3", 1)) {
     if (NW == 16) return launch_bwd_persist<G, 16, 16, true>(a, geo, p, grid, stream);
     if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, true>(a, geo, p, grid, stream)
@@ -668,7 +902,9 @@ size_t ft_rnn_workspace(int gates, int B, int H) {
   const int ngrp = 2 * ft_cdiv(B, MB);
   PersistWs f = carve_ws(nullptr, ngrp, H);
   PersistWs b = carve_ws(nullptr, ngrp, gates * H);
-  return f.total_bytes > b.total_bytes ? f.total_bytes : b.total_bytes;
+  PersistWs r = carve_ws_rs(nullptr, ngrp, H / 16);
+  size_t m = f.total_bytes > b.total_bytes ? f.total_bytes : b.total_bytes;
+  return r.total_bytes > m ? r.total_bytes : m;
 }
 
 int ft_rnn_set_persistent(int enabled) {
