@@ -72,6 +72,18 @@ __global__ __launch_bounds__(256) void ft_pack_weights_kernel(const FtPackDesc* 
   }
 }
 
+struct FtSegs {
+  const float* src[64];
+  float* dst[64];
+  long len[64];
+};
+__global__ __launch_bounds__(256) void ft_copy_segments_kernel(FtSegs sg) {
+  const float* s = sg.src[blockIdx.x];
+  float* d = sg.dst[blockIdx.x];
+  const long n = sg.len[blockIdx.x];
+  for (long i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+
 // ---- dropout (F.dropout, forward_tacotron.py:35 ; common_layers.py:106,110) -------------------------
 // Counter-based mask: keep(i) = hash(seed, i) >= p ; the backward re-derives the same mask from the seed,
 // so no mask tensor is stored.  out = keep ? x/(1-p) : 0
@@ -483,6 +495,20 @@ int ft_pack_weights(const FtPackDesc* descs, int n, long total_tiles, void* stre
   FT_REQUIRE(descs != nullptr, "pack_weights: null descriptor array");
   hipLaunchKernelGGL(ft_pack_weights_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, descs, n);
   return ft_check_launch("pack_weights");
+}
+
+int ft_copy_segments(const float* const* src, float* const* dst, const long* len, int n, void* stream) {
+  FT_REQUIRE(n >= 0 && n <= 64, "copy_segments: n=%d (max 64)", n);
+  if (n == 0) return FT_OK;
+  FtSegs sg;
+  for (int i = 0; i < n; ++i) {
+    FT_REQUIRE(len[i] >= 0 && (len[i] == 0 || (src[i] && dst[i])), "copy_segments: bad segment %d", i);
+    sg.src[i] = src[i];
+    sg.dst[i] = dst[i];
+    sg.len[i] = len[i];
+  }
+  hipLaunchKernelGGL(ft_copy_segments_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, sg);
+  return ft_check_launch("copy_segments");
 }
 
 int ft_dropout(const float* x, float* out, long n, float p, uint64_t seed, void* stream) {

@@ -660,6 +660,19 @@ def transpose_pad_bwd(dout: torch.Tensor, T: int) -> torch.Tensor:
     return dx
 
 
+def copy_segments(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor]) -> None:
+    """dsts[i] <- srcs[i] (contiguous fp32, equal numel), all in one launch (at most 64 pairs per launch)."""
+    for i in range(0, len(srcs), 64):
+        ss, dd = srcs[i:i + 64], dsts[i:i + 64]
+        n = len(ss)
+        for a, b in zip(ss, dd):
+            _chk(a, 'src'); _chk(b, 'dst')
+            if a.numel() != b.numel():
+                raise _lib.FtError('copy_segments: size mismatch')
+        lens = (ctypes.c_long * n)(*[a.numel() for a in ss])
+        _lib.call('ft_copy_segments', _ptr_array(ss), _ptr_array(dd), lens, n, _stream())
+
+
 def transpose2d(x: torch.Tensor) -> torch.Tensor:
     """[R,C] -> [C,R] (used for W_hh^T in BPTT)."""
     R, C = x.shape

@@ -122,6 +122,18 @@ def _emit_multi(ws, compute, deps=()):
     return [None] * len(ws)
 
 
+def _emit_copies(ws, values):
+    """_emit_copy for several parameters at once: one launch for all the slots the sink still has open."""
+    ents = [_sink_view(w) for w in ws]
+    outs = [v if e is None else None for e, v in zip(ents, values)]
+    todo = [(e, v) for e, v in zip(ents, values) if e is not None]
+    if todo:
+        H.copy_segments([v for _, v in todo], [e[1] for e, _ in todo])
+        for e, _ in todo:
+            _sink_done(e[0])
+    return outs
+
+
 def _emit_copy(w: torch.Tensor, value: torch.Tensor):
     """Small vector gradients that a fused kernel already produced in `value`."""
     ent = _sink_view(w)
@@ -286,8 +298,9 @@ class ConvBankFn(Function):
                 dptr = dy.data_ptr() + i * C * _F4
                 dws.append(_emit(ws[i], lambda out, dptr=dptr, Tvalid=Tvalid: H.conv1d_bwd_weight_raw(
                     dptr, K * C, x, out, T + 1, Tvalid), (dy, x)))
-        dgs = [_emit_copy(gs[i], dgamma[i * C:(i + 1) * C]) for i in range(K)]
-        dbs = [_emit_copy(bs[i], dbeta[i * C:(i + 1) * C]) for i in range(K)]
+        both = _emit_copies(list(gs) + list(bs), [dgamma[i * C:(i + 1) * C] for i in range(K)] +
+                            [dbeta[i * C:(i + 1) * C] for i in range(K)])
+        dgs, dbs = both[:K], both[K:]
         return (dx, None, None, None, None, None, *dws, *dgs, *dbs)
 
 
@@ -357,8 +370,10 @@ def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx):
     if dx is not None:          # both directions' input-projection data gradients in one chained launch
         H.linear_bwd_data_multi([dxp.data_ptr(), dxp.data_ptr() + GH * _F4], 2 * GH, [params[0], params[4]], dx,
                                 rows, GH, dy_tm_B=B, dx_tm_B=0)
+    gb = _emit_copies([params[2], params[3], params[6], params[7]],
+                      [dbx[0:GH], dbh[0:GH], dbx[GH:2 * GH], dbh[GH:2 * GH]])
     for d in range(2):
-        w_ih, w_hh, b_ih, b_hh = params[4 * d:4 * d + 4]
+        w_ih, w_hh = params[4 * d], params[4 * d + 1]
         px = dxp.data_ptr() + d * GH * _F4
         ph = dhp.data_ptr() + d * GH * _F4
         g_ih = _emit(w_ih, lambda out, px=px: H.linear_bwd_weight_raw(
@@ -366,9 +381,7 @@ def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx):
         g_hh = _emit(w_hh, lambda out, ph=ph, d=d: H.linear_bwd_weight_raw(
             ph, 2 * GH, hid.data_ptr() + d * Hh * _F4, 2 * Hh, out, rows, Hh, GH, B=B, T=T,
             x_shift=-1 if d == 0 else 1, dy_tm=True, x_tm=True), (dhp, hid))
-        g_bi = _emit_copy(b_ih, dbx[d * GH:(d + 1) * GH])
-        g_bh = _emit_copy(b_hh, dbh[d * GH:(d + 1) * GH])
-        grads += [g_ih, g_hh, g_bi, g_bh]
+        grads += [g_ih, g_hh, gb[2 * d], gb[2 * d + 1]]
     return dx, grads
 
 

@@ -189,6 +189,10 @@ int ft_colsum(const float* x, long ldx, float* out, int rows, int C, float scale
  * is the backward (no mask tensor).  torch's RNG stream cannot be matched: parity runs use p = 0. */
 int ft_dropout(const float* x, float* out, long n, float p, uint64_t seed, void* stream);
 int ft_scale(const float* x, float* out, long n, float s, void* stream);
+/* n <= 64 independent device-to-device copies in ONE launch: dst[i][0:len[i]] = src[i][0:len[i]]  (src / dst / len are
+ * HOST arrays).  Used to hand fused-kernel results (a conv bank's K dgamma / dbeta slices, an RNN's four bias
+ * gradients) to their slots in the flat gradient buffer without one copy launch per parameter. */
+int ft_copy_segments(const float* const* src, float* const* dst, const long* len, int n, void* stream);
 
 /* ---- nn.Embedding (forward_tacotron.py:18,31,73,133) -------------------------------------------------- */
 /* out[row,:] = w[idx[row],:] ; *err_flag set to 1 on an out-of-range index (row zero-filled) */
