@@ -48,7 +48,10 @@ def dominant_kernel_roofline(events):
     out = {'bound': 'mfma',
            'kernel': ('ft_gemm_rows_b3_kernel<2,2>' if b3 else 'ft_gemm_rows_kernel<2,2,NT>') + ' (postnet conv bank fwd)',
            'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-           'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+           'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+           # HBM-side bytes per launch from the PMC counters (profiles/r01e_pmc_bank_fwd.txt: FETCH_SIZE x 2 (gfx950
+           # correction for 16-B-per-lane reads) + WRITE_SIZE, separate rocprofv3 --pmc passes); algorithmic bytes 232 MB
+           'traffic': 401.6e6, 'traffic_unit': 'B/launch', 'algorithmic_bytes': 232.2e6,
            'launch_ms': round(ms, 4), 'launches_timed': len(events), 'flops_per_launch': flops}
     if b3:
         # fp32 work executed on the bf16 matrix pipe: every fp32 product = 6 bf16 MFMA products of an exact 3-way
