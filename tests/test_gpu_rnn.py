@@ -128,3 +128,36 @@ def test_full_width_lstm_long_sequence_persistent_equals_step():
     assert maxdiff(outs[1][0], outs[0][0]) < 1e-5 and maxdiff(outs[1][1], outs[0][1]) < 1e-4
     assert torch.isfinite(outs[1][2]).all()
     assert maxdiff(outs[1][2], outs[0][2]) < 1e-5
+
+
+@pytest.mark.parametrize('G,B,T,Hh', [(3, 32, 19, 64), (3, 21, 14, 128), (3, 32, 11, 256), (4, 32, 13, 128), (4, 9, 17, 64)])
+def test_reduce_scatter_backward_equals_all_gather(G, B, T, Hh, monkeypatch):
+    """The reduce-scatter form of the persistent backward (default only for G*H >= 1024) forced on at every width it
+    supports (FT_RNN_BWD_RS=2): 1 / 2 tiles per wave, the GRU's padded k-block, ragged lengths, B % 16 != 0 -- against
+    the all-gather form (FT_RNN_BWD_RS=0).  Same products, different summation order: fp32 rounding noise only."""
+    from forwardtacotron_amd import hip as H
+    g = torch.Generator().manual_seed(G * 100 + Hh + B)
+    xp = (torch.randn(T, B, 2 * G * Hh, generator=g) * 0.5).cuda()
+    whh = [(torch.randn(G * Hh, Hh, generator=g) * (1.5 / Hh ** 0.5)).cuda() for _ in range(2)]
+    bhh = [(torch.randn(G * Hh, generator=g) * 0.1).cuda() for _ in range(2)]
+    dout = (torch.randn(T, B, 2 * Hh, generator=g) * 0.1).cuda()
+    lens = None
+    if G == 4:
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        lens[0] = T
+        lens = lens.cuda()
+        raw, cst, gates = H.lstm_fwd(xp, whh[0], whh[1], bhh[0], bhh[1], lens, Hh, True)
+    else:
+        out, gates = H.gru_fwd(xp, whh[0], whh[1], bhh[0], bhh[1], Hh, True)
+    wt = [H.transpose2d(w) for w in whh]
+    res = {}
+    for mode in ('2', '0'):
+        monkeypatch.setenv('FT_RNN_BWD_RS', mode)
+        if G == 4:
+            res[mode] = (H.lstm_bwd(dout, raw, cst, gates, wt[0], wt[1], lens, Hh).cpu(),)
+        else:
+            res[mode] = tuple(t.cpu() for t in H.gru_bwd(dout, out, gates, wt[0], wt[1], Hh))
+        H.check_rnn_status()
+    for a, b in zip(res['2'], res['0']):
+        assert torch.isfinite(a).all()
+        assert maxdiff(a, b) < 2e-6 * max(1.0, float(b.abs().max()))
