@@ -333,8 +333,12 @@ int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float
   a.vec = (H % 4 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)whh_f % 16 == 0) && ((uintptr_t)whh_r % 16 == 0);
   const bool fast = a.vec && (H % 16 == 0);
   {
-    const int rc = ft_rnn_fwd_persistent(G, a, ws, ws_bytes, stream);
+    const int rc = ft_rnn_fwd_persistent(G, a, ws, ws_bytes, stream);      // writes the zeros of finished items itself
     if (rc != -1) return rc;
+  }
+  if (lens) {   // inactive positions must read as zeros
+    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * T * 2 * H, stream);
+    if (cst) (void)hipMemsetAsync(cst, 0, sizeof(float) * (size_t)B * T * 2 * H, stream);
   }
   constexpr int UB = 16 / G;
   const bool two = B > 16;                        // 32 batch rows per workgroup when there are that many
@@ -373,8 +377,12 @@ int rnn_bwd(const float* dout, const float* out, const float* cst, const float* 
           ((uintptr_t)whhT_r % 16 == 0);
   const bool fast = a.vec && (((long)G * H) % 16 == 0);
   {
-    const int rc = ft_rnn_bwd_persistent(G, a, ws, ws_bytes, stream);
+    const int rc = ft_rnn_bwd_persistent(G, a, ws, ws_bytes, stream);      // writes the zeros of finished items itself
     if (rc != -1) return rc;
+  }
+  if (lens) {
+    (void)hipMemsetAsync(dxp, 0, sizeof(float) * (size_t)B * T * 2 * G * H, stream);
+    if (dhp != dxp) (void)hipMemsetAsync(dhp, 0, sizeof(float) * (size_t)B * T * 2 * G * H, stream);
   }
   dim3 grid(ft_cdiv(H, 16), ft_cdiv(B, 16), 2);
   const int ngroups = ft_cdiv((long)G * H, 16);
@@ -412,10 +420,6 @@ int ft_lstm_fwd(const float* xp, const float* whh_f, const float* whh_r, const f
                 void* workspace, size_t workspace_bytes, void* stream) {
   FT_REQUIRE(B > 0 && T >= 0 && H > 0, "lstm_fwd: bad dims");
   hipStream_t s = (hipStream_t)stream;
-  if (lens) {   // inactive positions must read as zeros
-    (void)hipMemsetAsync(out_raw, 0, sizeof(float) * (size_t)B * T * 2 * H, s);
-    (void)hipMemsetAsync(cstate, 0, sizeof(float) * (size_t)B * T * 2 * H, s);
-  }
   return rnn_fwd<4>(xp, whh_f, whh_r, bhh_f, bhh_r, out_raw, cstate, gates, lens, B, T, H, workspace,
                     workspace_bytes, s);
 }
@@ -425,7 +429,6 @@ int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, co
                 int H, void* workspace, size_t workspace_bytes, void* stream) {
   FT_REQUIRE(B > 0 && T >= 0 && H > 0, "lstm_bwd: bad dims");
   hipStream_t s = (hipStream_t)stream;
-  if (lens) (void)hipMemsetAsync(dgates, 0, sizeof(float) * (size_t)B * T * 2 * 4 * H, s);
   return rnn_bwd<4>(dout, out_raw, cstate, gates, whhT_f, whhT_r, dgates, dgates, carry, lens, B, T, H, workspace,
                     workspace_bytes, s);
 }

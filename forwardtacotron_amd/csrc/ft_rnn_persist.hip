@@ -313,6 +313,10 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
         float* gs = a.gates + (((long)ct * a.B + cb) * a.ND + d) * 4 * H + cun;
         gs[0] = sg[0]; gs[H] = sg[1]; gs[2 * H] = sg[2]; gs[3 * H] = sg[3];
       }
+    } else if (cthr) {                                   // finished item: positions t >= L read as zeros (t = s, both directions)
+      const long o = ((long)s * a.B + cb) * ldo + (long)d * H + cun;
+      a.out[o] = 0.f;
+      if (G == 4) a.cst[o] = 0.f;
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) xg[g] = xn[g];
@@ -518,6 +522,14 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
         float* dhh = a.dhp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
         dhh[0] = dgx[0]; dhh[H] = dgx[1]; dhh[2 * H] = dgh2;
       }
+    } else if (cthr) {       // finished item: zero gradient at t >= L (t = s in both directions)
+      float* dx = a.dxp + ((long)s * a.B + cb) * ldg + (long)d * K + cun;
+#pragma unroll
+      for (int g = 0; g < G; ++g) dx[(long)g * H] = 0.f;
+      if (G == 3) {
+        float* dhh = a.dhp + ((long)s * a.B + cb) * ldg + (long)d * K + cun;
+        dhh[0] = 0.f; dhh[H] = 0.f; dhh[2 * H] = 0.f;
+      }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) gv[g] = ngv[g];
@@ -704,6 +716,14 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
       if (G == 3) {
         float* dhh = a.dhp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
         dhh[0] = dgx[0]; dhh[H] = dgx[1]; dhh[2 * H] = dgh2;
+      }
+    } else if (cthr) {       // finished item: zero gradient at t >= L (t = s in both directions)
+      float* dx = a.dxp + ((long)s * a.B + cb) * ldg + (long)d * K + cun;
+#pragma unroll
+      for (int g = 0; g < G; ++g) dx[(long)g * H] = 0.f;
+      if (G == 3) {
+        float* dhh = a.dhp + ((long)s * a.B + cb) * ldg + (long)d * K + cun;
+        dhh[0] = 0.f; dhh[H] = 0.f; dhh[2 * H] = 0.f;
       }
     }
 #pragma unroll
