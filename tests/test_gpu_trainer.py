@@ -65,3 +65,55 @@ def test_dropout_is_seeded_and_scaled():
     keep = float((a > 0).float().mean())
     assert 0.48 < keep < 0.52
     assert set(a.unique().tolist()) == {0.0, 2.0}
+
+
+MID = dict(embed_dims=64, series_embed_dims=32, num_chars=135,
+           durpred_conv_dims=64, durpred_rnn_dims=32, durpred_dropout=0.0,
+           pitch_conv_dims=64, pitch_rnn_dims=32, pitch_dropout=0.0, pitch_strength=1.0,
+           energy_conv_dims=64, energy_rnn_dims=32, energy_dropout=0.0, energy_strength=1.0,
+           rnn_dims=256, prenet_dims=128, prenet_k=5, postnet_num_highways=2,
+           prenet_dropout=0.0, postnet_dims=128, postnet_k=4, prenet_num_highways=2,
+           postnet_dropout=0.0, n_mels=80)
+
+
+def test_mid_size_train_step_vs_oracle():
+    """One optimisation step through TrainStep at sizes where the wide paths run -- 128x128 bf16-split GEMM tiles
+    (forward, data and weight gradients), conv-bank weight gradients from one launch (C % 128 == 0), persistent
+    recurrences incl. the reduce-scatter backward (G*H = 1024), one-launch weight packs, token-side weight gradients on
+    the main stream -- against the CPU oracle's step: losses, gradient norm, every parameter after Adam, BN statistics."""
+    from forwardtacotron_amd import hip as H
+    from forwardtacotron_amd.model import ForwardTacotron
+    from forwardtacotron_amd.trainer import TrainStep
+    from oracle import ft_oracle as O
+    torch.manual_seed(21)
+    m = ForwardTacotron(**MID)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    batch = O.synthetic_batch(B=8, Tmax=96, n_mels=80, seed=4)
+    assert int(batch['mel_len'].max()) * 8 > 4000          # enough rows for the wide tiles
+    lr = 1e-3
+    newP, _, info = O.train_step(P, {}, {k: v.clone() for k, v in batch.items()}, MID, TRAIN_CFG, lr, 1)
+    m = m.cuda()
+    ts = TrainStep(m, lr=lr, train_cfg=TRAIN_CFG)
+    out = ts.step({k: v.clone().cuda() for k, v in batch.items()})
+    H.check_rnn_status()
+    assert abs(float(out['loss']) - float(info['losses']['loss'])) < 5e-5
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+        assert abs(float(out[k]) - float(info['losses'][k])) < 5e-5, k
+    gn = float(info['grad_norm']) if 'grad_norm' in info else None
+    if gn is not None:
+        assert abs(float(out['grad_norm']) - gn) < 2e-4 * max(1.0, gn)
+    sd = m.state_dict()
+    worst, worst_k = 0.0, None
+    for k, v in newP.items():
+        if v.dtype.is_floating_point:
+            # Adam's first step moves every weight by ~lr * sign(g): compare where the gradient is not rounding noise
+            d = maxdiff(sd[k].cpu(), v)
+            if 'running_' in k:
+                assert d < 1e-5 * max(1.0, float(v.abs().max())), k
+            elif k in info['grads']:
+                big = info['grads'][k].abs() > 1e-6
+                if bool(big.any()):
+                    d = float((sd[k].cpu() - v).abs()[big].max())
+                    if d > worst:
+                        worst, worst_k = d, k
+    assert worst < 1e-4, (worst, worst_k)
