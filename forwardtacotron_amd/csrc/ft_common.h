@@ -37,3 +37,14 @@ __device__ __forceinline__ double ft_wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
 }
+
+// counter-based dropout mask (ft_dropout and the kernels that fuse it): element i of a tensor is kept iff u(seed, i) >= p;
+// the backward re-derives the same mask from the seed, so no mask tensor is stored
+__device__ __forceinline__ uint32_t ft_hash32(uint64_t v) {
+  v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
+  return (uint32_t)v;
+}
+__device__ __forceinline__ bool ft_dropout_keep(uint64_t seed, long i, float p) {
+  const uint32_t h = ft_hash32(seed * 0x9e3779b97f4a7c15ULL + (uint64_t)i);
+  return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}

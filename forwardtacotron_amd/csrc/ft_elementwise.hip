@@ -87,17 +87,11 @@ __global__ __launch_bounds__(256) void ft_copy_segments_kernel(FtSegs sg) {
 // ---- dropout (F.dropout, forward_tacotron.py:35 ; common_layers.py:106,110) -------------------------
 // Counter-based mask: keep(i) = hash(seed, i) >= p ; the backward re-derives the same mask from the seed,
 // so no mask tensor is stored.  out = keep ? x/(1-p) : 0
-__device__ __forceinline__ uint32_t ft_hash32(uint64_t v) {
-  v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
-  return (uint32_t)v;
-}
 __global__ void ft_dropout_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float p,
                                   uint64_t seed) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t h = ft_hash32(seed * 0x9e3779b97f4a7c15ULL + (uint64_t)i);
-  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-  out[i] = u >= p ? x[i] / (1.0f - p) : 0.f;
+  out[i] = ft_dropout_keep(seed, i, p) ? x[i] / (1.0f - p) : 0.f;
 }
 __global__ void ft_scale_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float s) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

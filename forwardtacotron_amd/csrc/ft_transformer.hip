@@ -57,32 +57,45 @@ __global__ __launch_bounds__(256) void ft_softmax_bwd_kernel(const float* __rest
   for (int k = lane; k < Tk; k += 64) d[k] = scale * p[k] * (d[k] - dot);
 }
 
-// s = x (+ res) ; y = (s - mean)/sqrt(var + eps) * gamma + beta ; per-row mean / rstd saved
+// s = x (+ dropout_p(res)) ; y = (s - mean)/sqrt(var + eps) * gamma + beta ; per-row mean / rstd saved.
+// p > 0: the residual branch goes through F.dropout on the fly (mask index = flat index of the element, the same
+// counter-based mask ft_dropout would apply to `res`), FFTBlock's  norm(src + dropout(src2))  in one pass.
 __global__ __launch_bounds__(256) void ft_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ sum_out,
                                                                float* __restrict__ y, float* __restrict__ mean,
-                                                               float* __restrict__ rstd, long rows, int D, float eps) {
+                                                               float* __restrict__ rstd, long rows, int D, float eps,
+                                                               float p, uint64_t seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
   const float* xr = x + row * D;
   const float* rr = res ? res + row * D : nullptr;
+  const float keep_scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  auto elem = [&](int c) {
+    float v = xr[c];
+    if (rr) {
+      float r = rr[c];
+      if (p > 0.f) r = ft_dropout_keep(seed, row * D + c, p) ? r * keep_scale : 0.f;
+      v += r;
+    }
+    return v;
+  };
   float s1 = 0.f;
   for (int c = lane; c < D; c += 64) {
-    float v = xr[c] + (rr ? rr[c] : 0.f);
+    float v = elem(c);
     if (sum_out) sum_out[row * D + c] = v;
     s1 += v;
   }
   const float mu = wave_sum_all(s1) / (float)D;
   float s2 = 0.f;
   for (int c = lane; c < D; c += 64) {
-    float v = xr[c] + (rr ? rr[c] : 0.f) - mu;
+    float v = elem(c) - mu;
     s2 += v * v;
   }
   const float rs = 1.0f / sqrtf(wave_sum_all(s2) / (float)D + eps);
   for (int c = lane; c < D; c += 64) {
-    float v = xr[c] + (rr ? rr[c] : 0.f);
+    float v = elem(c);
     y[row * D + c] = (v - mu) * rs * gamma[c] + beta[c];
   }
   if (lane == 0) {
@@ -91,16 +104,19 @@ __global__ __launch_bounds__(256) void ft_layernorm_fwd_kernel(const float* __re
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma ; also t_xhat = dy*xhat (for dgamma via column sums)
+// dx = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma ; also t_xhat = dy*xhat (for dgamma via column sums);
+// dres (optional) = the gradient of the dropped-out residual branch = mask * dx / (1-p)
 __global__ __launch_bounds__(256) void ft_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               float* __restrict__ dx, float* __restrict__ dy_xhat, long rows,
-                                                               int D) {
+                                                               float* __restrict__ dx, float* __restrict__ dy_xhat,
+                                                               float* __restrict__ dres, long rows, int D, float p,
+                                                               uint64_t seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
   const float mu = mean[row], rs = rstd[row];
+  const float keep_scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   float a = 0.f, b = 0.f;
   for (int c = lane; c < D; c += 64) {
     float xh = (s[row * D + c] - mu) * rs;
@@ -113,8 +129,10 @@ __global__ __launch_bounds__(256) void ft_layernorm_bwd_kernel(const float* __re
   for (int c = lane; c < D; c += 64) {
     float xh = (s[row * D + c] - mu) * rs;
     float d = dy[row * D + c];
-    dx[row * D + c] = rs * (d * gamma[c] - a - xh * b);
+    const float g = rs * (d * gamma[c] - a - xh * b);
+    dx[row * D + c] = g;
     dy_xhat[row * D + c] = d * xh;
+    if (dres) dres[row * D + c] = (p > 0.f && !ft_dropout_keep(seed, row * D + c, p)) ? 0.f : g * keep_scale;
   }
 }
 
@@ -180,18 +198,22 @@ int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int
 }
 
 int ft_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* sum_out,
-                     float* y, float* mean, float* rstd, long rows, int D, float eps, void* stream) {
+                     float* y, float* mean, float* rstd, long rows, int D, float eps, float res_dropout_p,
+                     uint64_t res_dropout_seed, void* stream) {
+  FT_REQUIRE(res_dropout_p >= 0.f && res_dropout_p < 1.f, "layernorm_fwd: dropout p must be in [0,1)");
   if (rows <= 0 || D <= 0) return FT_OK;
   hipLaunchKernelGGL(ft_layernorm_fwd_kernel, dim3(ft_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-                     beta, sum_out, y, mean, rstd, rows, D, eps);
+                     beta, sum_out, y, mean, rstd, rows, D, eps, res_dropout_p, res_dropout_seed);
   return ft_check_launch("layernorm_fwd");
 }
 
 int ft_layernorm_bwd(const float* dy, const float* s, const float* gamma, const float* mean, const float* rstd,
-                     float* dx, float* dy_xhat, long rows, int D, void* stream) {
+                     float* dx, float* dy_xhat, float* dres, long rows, int D, float res_dropout_p,
+                     uint64_t res_dropout_seed, void* stream) {
+  FT_REQUIRE(res_dropout_p >= 0.f && res_dropout_p < 1.f, "layernorm_bwd: dropout p must be in [0,1)");
   if (rows <= 0 || D <= 0) return FT_OK;
   hipLaunchKernelGGL(ft_layernorm_bwd_kernel, dim3(ft_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, s, gamma,
-                     mean, rstd, dx, dy_xhat, rows, D);
+                     mean, rstd, dx, dy_xhat, dres, rows, D, res_dropout_p, res_dropout_seed);
   return ft_check_launch("layernorm_bwd");
 }
 

@@ -103,11 +103,13 @@ class MHAFn(Function):
 
 
 class AddLayerNormFn(Function):
-    """LayerNorm(x + res)  (FFTBlock: src = norm(src + dropout(src2)), common_layers.py:175-176,181-183);
-    res=None: plain LayerNorm (ForwardTransformer.norm, :217)."""
+    """LayerNorm(x + dropout_p(res))  (FFTBlock: src = norm(src + dropout(src2)), common_layers.py:175-176,181-183) in
+    one pass: the dropout of the residual branch uses the same counter-based mask as ops.DropoutFn, applied while the
+    rows are normalised (no separate dropout pass forward or backward).  res=None: plain LayerNorm
+    (ForwardTransformer.norm, :217)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps):
+    def forward(ctx, x, res, gamma, beta, eps, p=0.0, seed=0):
         x = _c(x)
         D = x.shape[-1]
         rows = x.numel() // D
@@ -115,11 +117,13 @@ class AddLayerNormFn(Function):
         y = torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=x.dtype)
         rstd = torch.empty(rows, device=x.device, dtype=x.dtype)
+        p = float(p) if res is not None else 0.0
         _lib.call('ft_layernorm_fwd', x.data_ptr(), _p(_c(res) if res is not None else None), gamma.data_ptr(),
                   beta.data_ptr(), s.data_ptr() if res is not None else None, y.data_ptr(), mean.data_ptr(),
-                  rstd.data_ptr(), rows, D, float(eps), H._stream())
+                  rstd.data_ptr(), rows, D, float(eps), p, int(seed), H._stream())
         ctx.save_for_backward(s, gamma, beta, mean, rstd)
         ctx.has_res = res is not None
+        ctx.p, ctx.seed = p, int(seed)
         return y
 
     @staticmethod
@@ -130,11 +134,12 @@ class AddLayerNormFn(Function):
         rows = s.numel() // D
         dx = torch.empty_like(s)
         t = torch.empty_like(s)
+        dres = torch.empty_like(s) if ctx.has_res and ctx.p > 0 else None
         _lib.call('ft_layernorm_bwd', dy.data_ptr(), s.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                  dx.data_ptr(), t.data_ptr(), rows, D, H._stream())
+                  dx.data_ptr(), t.data_ptr(), _p(dres), rows, D, ctx.p, ctx.seed, H._stream())
         dg = _emit(gamma, lambda o: H.colsum_raw(t.data_ptr(), D, o, rows, D), heavy=False)
         db = _emit(beta, lambda o: H.colsum_raw(dy.data_ptr(), D, o, rows, D), heavy=False)
-        return dx, (dx if ctx.has_res else None), dg, db, None
+        return dx, ((dres if dres is not None else dx) if ctx.has_res else None), dg, db, None, None, None
 
 
 class ConvBiasFn(Function):
@@ -242,12 +247,13 @@ class FFTBlock(nn.Module):
         seed = _seed() if p > 0 else 0
         src2 = MHAFn.apply(src, key_pad, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
                            self.nhead, p, seed)
-        src2 = _dropout(src2, self.p, self.training)
-        src = AddLayerNormFn.apply(src, src2, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # the two F.dropout of the residual branches (common_layers.py:175,182) are fused into the LayerNorm kernels
+        src = AddLayerNormFn.apply(src, src2, self.norm1.weight, self.norm1.bias, self.norm1.eps, p,
+                                   _seed() if p > 0 else 0)
         src2 = ConvBiasFn.apply(src, self.conv1.weight, self.conv1.bias, True)
         src2 = ConvBiasFn.apply(src2, self.conv2.weight, self.conv2.bias, False)
-        src2 = _dropout(src2, self.p, self.training)
-        return AddLayerNormFn.apply(src, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return AddLayerNormFn.apply(src, src2, self.norm2.weight, self.norm2.bias, self.norm2.eps, p,
+                                    _seed() if p > 0 else 0)
 
 
 class ForwardTransformer(nn.Module):

@@ -139,10 +139,15 @@ int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int
 /* nn.LayerNorm(D) over the last dim with an optional fused residual add: s = x (+res) (stored to sum_out if not
  * NULL), y = LN(s); per-row mean / rstd saved.  bwd: dx (gradient wrt s) and dy_xhat = dy*xhat whose column
  * sums are dgamma (dbeta = column sums of dy), via ft_colsum. */
+/* res_dropout_p > 0: the residual branch is F.dropout(res, p) computed on the fly with ft_dropout's counter-based mask
+ * (seed, flat element index) -- FFTBlock's norm(src + dropout(src2)) (common_layers.py:175-176,181-183) in one pass;
+ * the backward then also writes dres = d/d(res) = mask * dx / (1-p) (dres may be NULL). */
 int ft_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* sum_out,
-                     float* y, float* mean, float* rstd, long rows, int D, float eps, void* stream);
+                     float* y, float* mean, float* rstd, long rows, int D, float eps, float res_dropout_p,
+                     uint64_t res_dropout_seed, void* stream);
 int ft_layernorm_bwd(const float* dy, const float* s, const float* gamma, const float* mean, const float* rstd,
-                     float* dx, float* dy_xhat, long rows, int D, void* stream);
+                     float* dx, float* dy_xhat, float* dres, long rows, int D, float res_dropout_p,
+                     uint64_t res_dropout_seed, void* stream);
 /* PositionalEncoding (common_layers.py:127-145): out = x + scale[0]*pe[t,:]; dscale = sum(dout*pe) */
 int ft_posenc_fwd(const float* x, const float* pe, const float* scale, float* out, int B, int T, int D,
                   void* stream);

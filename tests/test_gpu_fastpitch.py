@@ -119,6 +119,31 @@ def test_add_layernorm(rows, D, res):
         assert maxdiff(a.grad.cpu(), b.grad) < 5e-5 * max(1.0, float(b.grad.abs().max()))
 
 
+@pytest.mark.parametrize('rows,D,p', [(33, 24, 0.3), (300, 384, 0.1)])
+def test_add_layernorm_with_fused_dropout_equals_separate_dropout(rows, D, p):
+    """norm(x + dropout(res)) in one kernel == DropoutFn (same seed, same counter-based mask) followed by the plain
+    AddLayerNorm: outputs and all four gradients identical (pure refactoring of where the mask is applied)."""
+    from forwardtacotron_amd.fastpitch import AddLayerNormFn
+    from forwardtacotron_amd.ops import DropoutFn
+    g = torch.Generator().manual_seed(rows * 3 + D)
+    x, r, w = (torch.randn(2, rows, D, generator=g) for _ in range(3))
+    gamma = 1 + 0.2 * torch.randn(D, generator=g)
+    beta = 0.1 * torch.randn(D, generator=g)
+    seed = 987654321
+    outs = []
+    for fused in (True, False):
+        xs, rs, gs, bs = (t.clone().cuda().requires_grad_(True) for t in (x, r, gamma, beta))
+        if fused:
+            y = AddLayerNormFn.apply(xs, rs, gs, bs, 1e-5, p, seed)
+        else:
+            y = AddLayerNormFn.apply(xs, DropoutFn.apply(rs, p, seed), gs, bs, 1e-5)
+        (y * w.cuda()).sum().backward()
+        outs.append([y.detach().cpu()] + [t.grad.cpu() for t in (xs, rs, gs, bs)])
+    assert float((outs[0][2] == 0).float().mean()) > 0.5 * p            # the mask really dropped gradient entries
+    for a, b in zip(*outs):
+        assert maxdiff(a, b) < 1e-6 * max(1.0, float(b.abs().max()))
+
+
 @pytest.mark.parametrize('Cin,Cout,k,relu', [(16, 24, 5, True), (24, 16, 1, False), (7, 9, 3, True), (256, 1024, 9, True)])
 def test_conv_bias(Cin, Cout, k, relu):
     from forwardtacotron_amd.fastpitch import ConvBiasFn
