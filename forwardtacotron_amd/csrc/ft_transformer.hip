@@ -20,7 +20,8 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 // P[row, :] = softmax(scale * S[row, :] + mask) in place; row = ((b*nh + h)*Tq + q); key k masked when
 // key_pad[b*Tk + k] != 0 (nn.MultiheadAttention key_padding_mask, common_layers.py:172-174)
 __global__ __launch_bounds__(256) void ft_softmax_fwd_kernel(float* __restrict__ S, const unsigned char* __restrict__ key_pad,
-                                                             long rows, int rows_per_b, int Tk, float scale) {
+                                                             long rows, int rows_per_b, int Tk, float scale,
+                                                             float* __restrict__ dropped, float p, uint64_t seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
@@ -40,21 +41,40 @@ __global__ __launch_bounds__(256) void ft_softmax_fwd_kernel(float* __restrict__
   }
   sum = wave_sum_all(sum);
   const float inv = 1.0f / sum;
-  for (int k = lane; k < Tk; k += 64) s[k] *= inv;
+  if (dropped) {      // attention dropout (nn.MultiheadAttention(dropout=p)) in the same pass: mask index = flat index
+    const float ks = 1.0f / (1.0f - p);
+    float* dr = dropped + row * Tk;
+    for (int k = lane; k < Tk; k += 64) {
+      const float v = s[k] * inv;
+      s[k] = v;
+      dr[k] = ft_dropout_keep(seed, row * Tk + k, p) ? v * ks : 0.f;
+    }
+  } else {
+    for (int k = lane; k < Tk; k += 64) s[k] *= inv;
+  }
 }
 
-// dS = scale * P * (dP - sum_k dP*P)   (in place on dP)
+// dS = scale * P * (dP' - sum_k dP'*P)   (in place on dP); p > 0: dP' = dropout-mask(dP) / (1-p), i.e. dP arrives as the
+// gradient of the DROPPED probabilities and the mask is re-derived here
 __global__ __launch_bounds__(256) void ft_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows,
-                                                             int Tk, float scale) {
+                                                             int Tk, float scale, float p, uint64_t seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
-  const float* p = P + row * Tk;
+  const float* pr = P + row * Tk;
   float* d = dP + row * Tk;
+  const float ks = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   float dot = 0.f;
-  for (int k = lane; k < Tk; k += 64) dot += d[k] * p[k];
+  for (int k = lane; k < Tk; k += 64) {
+    float g = d[k];
+    if (p > 0.f) {
+      g = ft_dropout_keep(seed, row * Tk + k, p) ? g * ks : 0.f;
+      d[k] = g;
+    }
+    dot += g * pr[k];
+  }
   dot = wave_sum_all(dot);
-  for (int k = lane; k < Tk; k += 64) d[k] = scale * p[k] * (d[k] - dot);
+  for (int k = lane; k < Tk; k += 64) d[k] = scale * pr[k] * (d[k] - dot);
 }
 
 // s = x (+ dropout_p(res)) ; y = (s - mean)/sqrt(var + eps) * gamma + beta ; per-row mean / rstd saved.
@@ -181,19 +201,22 @@ __global__ void ft_relu_bwd_kernel(const float* __restrict__ dy, const float* __
 extern "C" {
 
 int ft_softmax_fwd(float* scores, const unsigned char* key_pad, int B, int nh, int Tq, int Tk, float scale,
-                   void* stream) {
+                   float* dropped, float dropout_p, uint64_t dropout_seed, void* stream) {
+  FT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "softmax_fwd: dropout p must be in [0,1)");
   long rows = (long)B * nh * Tq;
   if (rows <= 0 || Tk <= 0) return FT_OK;
   hipLaunchKernelGGL(ft_softmax_fwd_kernel, dim3(ft_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, scores, key_pad,
-                     rows, nh * Tq, Tk, scale);
+                     rows, nh * Tq, Tk, scale, dropout_p > 0.f ? dropped : nullptr, dropout_p, dropout_seed);
   return ft_check_launch("softmax_fwd");
 }
 
-int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, float scale, void* stream) {
+int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, float scale, float dropout_p,
+                   uint64_t dropout_seed, void* stream) {
+  FT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "softmax_bwd: dropout p must be in [0,1)");
   long rows = (long)B * nh * Tq;
   if (rows <= 0 || Tk <= 0) return FT_OK;
   hipLaunchKernelGGL(ft_softmax_bwd_kernel, dim3(ft_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, probs, dprobs,
-                     rows, Tk, scale);
+                     rows, Tk, scale, dropout_p, dropout_seed);
   return ft_check_launch("softmax_bwd");
 }
 

@@ -55,19 +55,21 @@ class MHAFn(Function):
         q0 = qkv.data_ptr()
         _bgemm('nt', q0, 3 * d, T * 3 * d, hd, q0 + d * _F4, 3 * d, T * 3 * d, hd, P.data_ptr(), T, nh * T * T, T * T,
                T, T, hd, B, nh, x.device)
-        _lib.call('ft_softmax_fwd', P.data_ptr(), _p(key_pad), B, nh, T, T, scale, H._stream())
-        Pd = H.dropout(P, float(p_drop), int(seed)) if p_drop > 0 else P
+        # softmax and nn.MultiheadAttention's attention dropout in one pass; both P and dropout(P) are kept for backward
+        Pd = torch.empty_like(P) if p_drop > 0 else P
+        _lib.call('ft_softmax_fwd', P.data_ptr(), _p(key_pad), B, nh, T, T, scale, Pd.data_ptr() if p_drop > 0 else None,
+                  float(p_drop), int(seed), H._stream())
         att = torch.empty(B, T, d, device=x.device, dtype=x.dtype)
         _bgemm('nn', Pd.data_ptr(), T, nh * T * T, T * T, q0 + 2 * d * _F4, 3 * d, T * 3 * d, hd, att.data_ptr(), d,
                T * d, hd, T, hd, T, B, nh, x.device)
         out = H.linear_fwd(att, out_w, out_b)
-        ctx.save_for_backward(x, qkv, P, att, key_pad, in_w, in_b, out_w, out_b)
+        ctx.save_for_backward(x, qkv, P, att, key_pad, in_w, in_b, out_w, out_b, Pd)
         ctx.meta = (nh, hd, scale, float(p_drop), int(seed))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, qkv, P, att, key_pad, in_w, in_b, out_w, out_b = ctx.saved_tensors
+        x, qkv, P, att, key_pad, in_w, in_b, out_w, out_b, Pd = ctx.saved_tensors
         nh, hd, scale, p_drop, seed = ctx.meta
         dout = _c(dout)
         B, T, d = x.shape
@@ -77,7 +79,6 @@ class MHAFn(Function):
         g_ow = _emit(out_w, lambda o: H.linear_bwd_weight_raw(dout.data_ptr(), d, att.data_ptr(), d, o, rows, d, d),
                      (dout, att))
         g_ob = _emit(out_b, lambda o: H.colsum_raw(dout.data_ptr(), d, o, rows, d), heavy=False)
-        Pd = H.dropout(P, p_drop, seed) if p_drop > 0 else P
         q0 = qkv.data_ptr()
         dqkv = torch.empty_like(qkv)
         g0 = dqkv.data_ptr()
@@ -88,9 +89,8 @@ class MHAFn(Function):
         # dV_h = Pd^T dAtt_h
         _bgemm('tn', Pd.data_ptr(), T, nh * T * T, T * T, datt.data_ptr(), d, T * d, hd, g0 + 2 * d * _F4, 3 * d,
                T * 3 * d, hd, T, hd, T, B, nh, dev)
-        if p_drop > 0:
-            dP = H.dropout(dP, p_drop, seed)
-        _lib.call('ft_softmax_bwd', P.data_ptr(), dP.data_ptr(), B, nh, T, T, scale, H._stream())       # dP -> dS
+        # dPd -> dS: the dropout mask is re-derived inside the softmax gradient kernel
+        _lib.call('ft_softmax_bwd', P.data_ptr(), dP.data_ptr(), B, nh, T, T, scale, p_drop, seed, H._stream())
         # dQ_h = dS K_h ; dK_h = dS^T Q_h
         _bgemm('nn', dP.data_ptr(), T, nh * T * T, T * T, q0 + d * _F4, 3 * d, T * 3 * d, hd, g0, 3 * d, T * 3 * d, hd,
                T, hd, T, B, nh, dev)

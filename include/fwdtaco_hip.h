@@ -133,9 +133,13 @@ int ft_bgemm_tn(const float* A, long lda, long sA0, long sA1, const float* Bm, l
                 size_t workspace_bytes, void* stream);
 /* scores[B,nh,Tq,Tk] <- softmax(scale*scores + mask) in place; key_pad[B,Tk] bytes (non-zero = padded key) or NULL */
 int ft_softmax_fwd(float* scores, const unsigned char* key_pad, int B, int nh, int Tq, int Tk, float scale,
-                   void* stream);
-/* dprobs <- scale * P * (dprobs - rowsum(dprobs*P)) in place */
-int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, float scale, void* stream);
+                   float* dropped, float dropout_p, uint64_t dropout_seed, void* stream);
+/* dprobs <- scale * P * (dprobs' - rowsum(dprobs'*P)) in place; dropout_p > 0: dprobs arrives as the gradient of the
+ * DROPPED probabilities and dprobs' = mask * dprobs / (1-p) is formed here (same seed as the forward).
+ * Forward: dropout_p > 0 also writes dropped = F.dropout(P, p) (nn.MultiheadAttention's attention dropout) with
+ * ft_dropout's counter-based mask over the flat [B,nh,Tq,Tk] index, in the same pass. */
+int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, float scale, float dropout_p,
+                   uint64_t dropout_seed, void* stream);
 /* nn.LayerNorm(D) over the last dim with an optional fused residual add: s = x (+res) (stored to sum_out if not
  * NULL), y = LN(s); per-row mean / rstd saved.  bwd: dx (gradient wrt s) and dy_xhat = dy*xhat whose column
  * sums are dgamma (dbeta = column sums of dy), via ft_colsum. */
