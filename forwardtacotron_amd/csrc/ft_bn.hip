@@ -81,7 +81,12 @@ __global__ __launch_bounds__(256) void ft_col_partial_kernel(const float* __rest
 // mode 2 with 16-B lanes (C % 4 == 0, 16-B aligned rows): 16 row lanes x 16 column quads per block, four rows in
 // flight per lane; the 16 row-lane sums are combined in fixed order
 __global__ __launch_bounds__(256) void ft_colsum4_partial_kernel(const float* __restrict__ x, long ldx, long rows, int C,
-                                                                 int rows_per_chunk, double* __restrict__ partial) {
+                                                                 int rows_per_chunk, double* __restrict__ partial,
+                                                                 const float* __restrict__ x1) {
+  if (x1) {      // second matrix of the same shape -> slot 1 (block-uniform: blockIdx.z selects the matrix)
+    if (blockIdx.z == 1) x = x1;
+  }
+  const int slot = x1 ? (int)blockIdx.z : 0;
   __shared__ double red[16][65];
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + cq * 4;
@@ -115,8 +120,8 @@ __global__ __launch_bounds__(256) void ft_colsum4_partial_kernel(const float* __
       double a = 0.0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) a += red[i][threadIdx.x];
-      partial[((long)blockIdx.y * C + cc) * 2 + 0] = a;
-      partial[((long)blockIdx.y * C + cc) * 2 + 1] = 0.0;
+      partial[((long)blockIdx.y * C + cc) * 2 + slot] = a;
+      if (!x1) partial[((long)blockIdx.y * C + cc) * 2 + 1] = 0.0;
     }
   }
 }
@@ -503,13 +508,33 @@ int ft_colsum(const float* x, long ldx, float* out, int rows, int C, float scale
   ChunkPlan p = plan_chunks(rows, C);
   if (C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0)
     hipLaunchKernelGGL(ft_colsum4_partial_kernel, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, x, ldx, (long)rows, C,
-                       p.rows_per_chunk, (double*)workspace);
+                       p.rows_per_chunk, (double*)workspace, (const float*)nullptr);
   else
     hipLaunchKernelGGL(ft_col_partial_kernel<2>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, x, ldx, nullptr,
                        nullptr, nullptr, 1, rows, rows, C, 0, p.rows_per_chunk, (double*)workspace);
   hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, C, out, nullptr, scale, accumulate);
   return ft_check_launch("colsum");
+}
+
+// column sums of TWO matrices of one shape in one partial + one finalize launch (LayerNorm's dgamma / dbeta)
+int ft_colsum2(const float* x0, const float* x1, long ldx, float* out0, float* out1, int rows, int C, void* workspace,
+               size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(rows >= 0 && C >= 0, "colsum2: bad dims");
+  if (C == 0) return FT_OK;
+  const bool vec = C % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x0) % 16 == 0 && ((uintptr_t)x1) % 16 == 0;
+  if (rows == 0 || !vec) {     // rare shapes: two plain calls
+    int rc = ft_colsum(x0, ldx, out0, rows, C, 1.0f, 0, workspace, workspace_bytes, stream);
+    return rc ? rc : ft_colsum(x1, ldx, out1, rows, C, 1.0f, 0, workspace, workspace_bytes, stream);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  FT_REQUIRE(workspace && workspace_bytes >= ft_colsum_workspace(rows, C), "colsum2: workspace too small");
+  ChunkPlan p = plan_chunks(rows, C);
+  hipLaunchKernelGGL(ft_colsum4_partial_kernel, dim3(ft_cdiv(C, 64), p.nchunks, 2), dim3(256), 0, s, x0, ldx, (long)rows,
+                     C, p.rows_per_chunk, (double*)workspace, x1);
+  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
+                     p.nchunks, C, out0, out1, 1.0f, 0);
+  return ft_check_launch("colsum2");
 }
 
 }  // extern "C"

@@ -19,7 +19,7 @@ from . import _lib
 from . import hip as H
 from . import ops
 from .model import LengthRegulator, NUM_CHARS_DEFAULT, PAD_VALUE, _dropout, _seed
-from .ops import _c, _emit
+from .ops import _c, _emit, _emit_multi
 
 _F4 = 4
 
@@ -137,8 +137,8 @@ class AddLayerNormFn(Function):
         dres = torch.empty_like(s) if ctx.has_res and ctx.p > 0 else None
         _lib.call('ft_layernorm_bwd', dy.data_ptr(), s.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                   dx.data_ptr(), t.data_ptr(), _p(dres), rows, D, ctx.p, ctx.seed, H._stream())
-        dg = _emit(gamma, lambda o: H.colsum_raw(t.data_ptr(), D, o, rows, D), heavy=False)
-        db = _emit(beta, lambda o: H.colsum_raw(dy.data_ptr(), D, o, rows, D), heavy=False)
+        dg, db = _emit_multi([gamma, beta], lambda o: H.colsum2_raw(t.data_ptr(), dy.data_ptr(), D, o[0], o[1], rows, D),
+                             heavy=False)
         return dx, ((dres if dres is not None else dx) if ctx.has_res else None), dg, db, None, None, None
 
 

@@ -473,6 +473,13 @@ def colsum_raw(x_ptr: int, ldx: int, out: torch.Tensor, rows: int, C: int, scale
     _lib.call('ft_colsum', x_ptr, ldx, _p(out), rows, C, scale, int(accumulate), _p(ws), ws.numel(), _stream())
 
 
+def colsum2_raw(x0_ptr: int, x1_ptr: int, ldx: int, out0: torch.Tensor, out1: torch.Tensor, rows: int, C: int) -> None:
+    """out0 = column sums of x0, out1 = of x1 (same [rows, C] shape, row stride ldx): one partial + one finalize launch"""
+    nbytes = _lib.query('ft_colsum_workspace', rows, C)
+    ws = workspace(nbytes, out0.device)
+    _lib.call('ft_colsum2', x0_ptr, x1_ptr, ldx, _p(out0), _p(out1), rows, C, _p(ws), ws.numel(), _stream())
+
+
 def colsum(x: torch.Tensor) -> torch.Tensor:
     _chk(x, 'x')
     C = x.shape[-1]

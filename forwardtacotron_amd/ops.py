@@ -97,14 +97,14 @@ def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
     return None
 
 
-def _emit_multi(ws, compute, deps=()):
+def _emit_multi(ws, compute, deps=(), heavy: bool = True):
     """_emit for several parameters whose gradients one launch produces together: compute(outs)."""
     ents = [_sink_view(w) for w in ws]
     if any(e is None for e in ents):
         outs = [torch.empty_like(w) for w in ws]
         compute(outs)
         return outs
-    side = _SINK.stream
+    side = _SINK.stream if heavy else None
     if side is not None and deps and deps[0].numel() // deps[0].shape[-1] <= _SINK.inline_rows:
         side = None
     views = [e[1] for e in ents]

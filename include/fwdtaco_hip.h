@@ -192,6 +192,10 @@ int ft_bn_fold_eval(const float* gamma, const float* beta, const float* running_
 size_t ft_colsum_workspace(int rows, int C);
 int ft_colsum(const float* x, long ldx, float* out, int rows, int C, float scale, int accumulate, void* workspace,
               size_t workspace_bytes, void* stream);
+/* column sums of two matrices of one shape (x0 -> out0, x1 -> out1) in one partial + one finalize launch: LayerNorm's
+ * dgamma = colsum(dy * xhat), dbeta = colsum(dy) */
+int ft_colsum2(const float* x0, const float* x1, long ldx, float* out0, float* out1, int rows, int C, void* workspace,
+               size_t workspace_bytes, void* stream);
 
 /* ---- F.dropout (forward_tacotron.py:35 ; common_layers.py:106,110) and scalar scale (x/alpha, :39) ----- */
 /* out = keep ? x/(1-p) : 0 with keep(i) = hash(seed,i) >= p; calling it on the gradient with the same seed
