@@ -366,7 +366,7 @@ int ft_bgemm_nt(const float* A, long lda, long sA0, long sA1, const float* Bm, l
 }
 
 int ft_bgemm_nn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
-                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, void* stream) {
+                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, int a_rows_padded, void* stream) {
   FT_REQUIRE(nb0 >= 1 && nb1 >= 1, "bgemm_nn: bad batch");
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
@@ -375,6 +375,7 @@ int ft_bgemm_nn(const float* A, long lda, long sA0, long sA1, const float* Bm, l
   t.lda = lda; t.ldb = ldb; t.ldc = ldc;
   t.M = M; t.N = N; t.K = K; t.taps = 1;
   t.amap = ft_rowmap_identity(M);
+  t.a_rowpad = a_rows_padded;
   set_batch(t, nb0, nb1, sA0, sA1, sB0, sB1, sC0, sC1);
   return ft_launch_gemm_rows(&b, 1, true, (hipStream_t)stream);
 }
@@ -401,10 +402,11 @@ size_t ft_bgemm_tn_workspace(int M, int N, int R, int nb0, int nb1) {
 }
 
 int ft_bgemm_tn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
-                long ldc, long sC0, long sC1, int M, int N, int R, int nb0, int nb1, void* workspace,
+                long ldc, long sC0, long sC1, int M, int N, int R, int nb0, int nb1, int rows_padded, void* workspace,
                 size_t workspace_bytes, void* stream) {
   FT_REQUIRE(nb0 >= 1 && nb1 >= 1, "bgemm_tn: bad batch");
   FtGemmTNTask t = bgemm_tn_task(A, lda, sA0, sA1, Bm, ldb, sB0, sB1, C, ldc, sC0, sC1, M, N, R, nb0, nb1);
+  t.rowpad = rows_padded;
   return ft_launch_gemm_tn(t, (float*)workspace, workspace_bytes / sizeof(float), (hipStream_t)stream);
 }
 

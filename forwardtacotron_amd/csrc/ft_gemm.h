@@ -38,6 +38,9 @@ struct FtGemmTask {
   FtRowMap amap;
   FtRowMap cmap;        // output row permutation (Tlog/bstride/tstride only); identity by default
   int relu, accumulate, a_vec, b_vec;
+  // NN form only: every row of A is readable up to the next multiple of 4 of K (values there are ignored), so a K that
+  // is not a multiple of 4 can still take the 16-B-load path
+  int a_rowpad;
   // strided batch (attention: one GEMM per (batch item, head)); only for single-task launches.
   // instance z = blockIdx.z -> (z0, z1) = (z / nz1, z % nz1); X += z0*sX0 + z1*sX1 (floats)
   int nz, nz1;
@@ -62,6 +65,8 @@ struct FtGemmTNTask {
   int M, N, R, taps;
   FtRowMap amap, bmap;
   int a_vec, b_vec, accumulate;
+  // rows of A / B are readable up to the next multiple of 4 of M / N (those columns only reach masked outputs)
+  int rowpad;
   // strided batch (see FtGemmTask); dst += z0*sD0 + z1*sD1
   int nz, nz1;
   long sA0, sA1, sB0, sB1, sD0, sD1;

@@ -189,7 +189,14 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
     for (int p = 0; p < PA; ++p) {
       const int ts = a_t[p] + shift;
       const bool ok = a_ok[p] & (ts >= 0) & (ts < Tvalid);
-      if constexpr (FAST) ra[p] = ld4_sel(a_row[p] + aoff, curA, ok & kok);
+      if constexpr (FAST) {
+        ra[p] = ld4_sel(a_row[p] + aoff, curA, ok & kok);
+        if (tK & 3) {                         // K % 4 != 0 (a_rowpad launches): whatever lies behind column K-1 is ignored
+          if (k + 1 >= tK) ra[p].y = 0.f;
+          if (k + 2 >= tK) ra[p].z = 0.f;
+          if (k + 3 >= tK) ra[p].w = 0.f;
+        }
+      }
       else ra[p] = ld4(a_row[p] + aoff, ok ? tK - k : 0, avec);
     }
     if constexpr (!BNC) {
@@ -653,7 +660,8 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   bool fast = true;
   for (int i = 0; i < ntasks; ++i) {
     const FtGemmTask& t = batch->t[i];
-    fast = fast && t.a_vec && t.b_vec && (t.K % 4 == 0) && (!b_ncontig || t.N % 4 == 0);
+    const bool k_ok = t.K % 4 == 0 || (b_ncontig && t.a_rowpad && t.lda >= ((t.K + 3) & ~3));
+    fast = fast && t.a_vec && t.b_vec && k_ok && (!b_ncontig || t.N % 4 == 0);
   }
 #define FT_ROWS_LAUNCH(TM_, BNC_)                                                                              \
   do {                                                                                                         \
@@ -710,7 +718,9 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   FT_REQUIRE(t.nz1 >= 1 && t.nz % t.nz1 == 0, "gemm_tn: bad batch split");
   t.a_vec = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0) && (t.sA0 % 4 == 0) && (t.sA1 % 4 == 0);
   t.b_vec = (t.ldb % 4 == 0) && (((uintptr_t)t.B) % 16 == 0) && (t.sB0 % 4 == 0) && (t.sB1 % 4 == 0);
-  const bool fast = t.a_vec && t.b_vec && (t.M % 4 == 0) && (t.N % 4 == 0);
+  const bool m_ok = t.M % 4 == 0 || (t.rowpad && t.lda >= ((t.M + 3) & ~3));
+  const bool n_ok = t.N % 4 == 0 || (t.rowpad && t.ldb >= ((t.N + 3) & ~3));
+  const bool fast = t.a_vec && t.b_vec && m_ok && n_ok;
   TNPlan p = plan_tn(t, fast);
   size_t need = (size_t)p.S * t.taps * t.nz * t.M * t.N;
   FT_REQUIRE(workspace && workspace_floats >= need, "gemm_tn: workspace too small (%zu < %zu floats)",

@@ -20,12 +20,12 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 // P[row, :] = softmax(scale * S[row, :] + mask) in place; row = ((b*nh + h)*Tq + q); key k masked when
 // key_pad[b*Tk + k] != 0 (nn.MultiheadAttention key_padding_mask, common_layers.py:172-174)
 __global__ __launch_bounds__(256) void ft_softmax_fwd_kernel(float* __restrict__ S, const unsigned char* __restrict__ key_pad,
-                                                             long rows, int rows_per_b, int Tk, float scale,
+                                                             long rows, int rows_per_b, int Tk, long ld, float scale,
                                                              float* __restrict__ dropped, float p, uint64_t seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
-  float* s = S + row * Tk;
+  float* s = S + row * ld;
   const unsigned char* kp = key_pad ? key_pad + (row / rows_per_b) * Tk : nullptr;
   float mx = -INFINITY;
   for (int k = lane; k < Tk; k += 64) {
@@ -43,26 +43,28 @@ __global__ __launch_bounds__(256) void ft_softmax_fwd_kernel(float* __restrict__
   const float inv = 1.0f / sum;
   if (dropped) {      // attention dropout (nn.MultiheadAttention(dropout=p)) in the same pass: mask index = flat index
     const float ks = 1.0f / (1.0f - p);
-    float* dr = dropped + row * Tk;
+    float* dr = dropped + row * ld;
     for (int k = lane; k < Tk; k += 64) {
       const float v = s[k] * inv;
       s[k] = v;
       dr[k] = ft_dropout_keep(seed, row * Tk + k, p) ? v * ks : 0.f;
     }
+    for (int k = Tk + lane; k < ld; k += 64) dr[k] = 0.f;
   } else {
     for (int k = lane; k < Tk; k += 64) s[k] *= inv;
   }
+  for (int k = Tk + lane; k < ld; k += 64) s[k] = 0.f;       // row padding reads as zeros
 }
 
 // dS = scale * P * (dP' - sum_k dP'*P)   (in place on dP); p > 0: dP' = dropout-mask(dP) / (1-p), i.e. dP arrives as the
 // gradient of the DROPPED probabilities and the mask is re-derived here
 __global__ __launch_bounds__(256) void ft_softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows,
-                                                             int Tk, float scale, float p, uint64_t seed) {
+                                                             int Tk, long ld, float scale, float p, uint64_t seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
-  const float* pr = P + row * Tk;
-  float* d = dP + row * Tk;
+  const float* pr = P + row * ld;
+  float* d = dP + row * ld;
   const float ks = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   float dot = 0.f;
   for (int k = lane; k < Tk; k += 64) {
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void ft_softmax_bwd_kernel(const float* __rest
   }
   dot = wave_sum_all(dot);
   for (int k = lane; k < Tk; k += 64) d[k] = scale * pr[k] * (d[k] - dot);
+  for (int k = Tk + lane; k < ld; k += 64) d[k] = 0.f;
 }
 
 // s = x (+ dropout_p(res)) ; y = (s - mean)/sqrt(var + eps) * gamma + beta ; per-row mean / rstd saved.
@@ -200,23 +203,25 @@ __global__ void ft_relu_bwd_kernel(const float* __restrict__ dy, const float* __
 
 extern "C" {
 
-int ft_softmax_fwd(float* scores, const unsigned char* key_pad, int B, int nh, int Tq, int Tk, float scale,
+int ft_softmax_fwd(float* scores, const unsigned char* key_pad, int B, int nh, int Tq, int Tk, long ld, float scale,
                    float* dropped, float dropout_p, uint64_t dropout_seed, void* stream) {
   FT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "softmax_fwd: dropout p must be in [0,1)");
+  FT_REQUIRE(ld >= Tk, "softmax_fwd: row stride smaller than the row");
   long rows = (long)B * nh * Tq;
   if (rows <= 0 || Tk <= 0) return FT_OK;
   hipLaunchKernelGGL(ft_softmax_fwd_kernel, dim3(ft_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, scores, key_pad,
-                     rows, nh * Tq, Tk, scale, dropout_p > 0.f ? dropped : nullptr, dropout_p, dropout_seed);
+                     rows, nh * Tq, Tk, ld, scale, dropout_p > 0.f ? dropped : nullptr, dropout_p, dropout_seed);
   return ft_check_launch("softmax_fwd");
 }
 
-int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, float scale, float dropout_p,
+int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, long ld, float scale, float dropout_p,
                    uint64_t dropout_seed, void* stream) {
   FT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "softmax_bwd: dropout p must be in [0,1)");
+  FT_REQUIRE(ld >= Tk, "softmax_bwd: row stride smaller than the row");
   long rows = (long)B * nh * Tq;
   if (rows <= 0 || Tk <= 0) return FT_OK;
   hipLaunchKernelGGL(ft_softmax_bwd_kernel, dim3(ft_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, probs, dprobs,
-                     rows, Tk, scale, dropout_p, dropout_seed);
+                     rows, Tk, ld, scale, dropout_p, dropout_seed);
   return ft_check_launch("softmax_bwd");
 }
 

@@ -28,15 +28,20 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def _bgemm(kind, A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC1, M, N, K, nb0, nb1, device):
+def _bgemm(kind, A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC1, M, N, K, nb0, nb1, device,
+           padded: bool = False):
+    """padded: the [T,T]-shaped operand is stored with its row stride rounded up to 4 (see MHAFn)"""
     if kind == 'tn':
         nbytes = _lib.query('ft_bgemm_tn_workspace', M, N, K, nb0, nb1)
         ws = H.workspace(nbytes, device)
         _lib.call('ft_bgemm_tn', A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC1, M, N, K, nb0, nb1,
-                  ws.data_ptr(), ws.numel(), H._stream())
+                  int(padded), ws.data_ptr(), ws.numel(), H._stream())
+    elif kind == 'nn':
+        _lib.call('ft_bgemm_nn', A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC1, M, N, K, nb0, nb1,
+                  int(padded), H._stream())
     else:
-        _lib.call('ft_bgemm_' + kind, A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC1, M, N, K, nb0,
-                  nb1, H._stream())
+        _lib.call('ft_bgemm_nt', A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC1, M, N, K, nb0, nb1,
+                  H._stream())
 
 
 class MHAFn(Function):
@@ -51,17 +56,20 @@ class MHAFn(Function):
         hd = d // nh
         scale = 1.0 / math.sqrt(hd)
         qkv = H.linear_fwd(x, in_w, in_b)                                   # [B,T,3d]
-        P = torch.empty(B, nh, T, T, device=x.device, dtype=x.dtype)
+        # the [T,T] score / probability matrices are kept with their row stride rounded up to 4 floats (pad columns
+        # are zeros): T = 841 frames would otherwise push four of the six attention GEMMs off the 16-B-load paths
+        Tp = (T + 3) // 4 * 4
+        P = torch.empty(B, nh, T, Tp, device=x.device, dtype=x.dtype)
         q0 = qkv.data_ptr()
-        _bgemm('nt', q0, 3 * d, T * 3 * d, hd, q0 + d * _F4, 3 * d, T * 3 * d, hd, P.data_ptr(), T, nh * T * T, T * T,
+        _bgemm('nt', q0, 3 * d, T * 3 * d, hd, q0 + d * _F4, 3 * d, T * 3 * d, hd, P.data_ptr(), Tp, nh * T * Tp, T * Tp,
                T, T, hd, B, nh, x.device)
         # softmax and nn.MultiheadAttention's attention dropout in one pass; both P and dropout(P) are kept for backward
         Pd = torch.empty_like(P) if p_drop > 0 else P
-        _lib.call('ft_softmax_fwd', P.data_ptr(), _p(key_pad), B, nh, T, T, scale, Pd.data_ptr() if p_drop > 0 else None,
-                  float(p_drop), int(seed), H._stream())
+        _lib.call('ft_softmax_fwd', P.data_ptr(), _p(key_pad), B, nh, T, T, Tp, scale,
+                  Pd.data_ptr() if p_drop > 0 else None, float(p_drop), int(seed), H._stream())
         att = torch.empty(B, T, d, device=x.device, dtype=x.dtype)
-        _bgemm('nn', Pd.data_ptr(), T, nh * T * T, T * T, q0 + 2 * d * _F4, 3 * d, T * 3 * d, hd, att.data_ptr(), d,
-               T * d, hd, T, hd, T, B, nh, x.device)
+        _bgemm('nn', Pd.data_ptr(), Tp, nh * T * Tp, T * Tp, q0 + 2 * d * _F4, 3 * d, T * 3 * d, hd, att.data_ptr(), d,
+               T * d, hd, T, hd, T, B, nh, x.device, padded=True)
         out = H.linear_fwd(att, out_w, out_b)
         ctx.save_for_backward(x, qkv, P, att, key_pad, in_w, in_b, out_w, out_b, Pd)
         ctx.meta = (nh, hd, scale, float(p_drop), int(seed))
@@ -82,20 +90,21 @@ class MHAFn(Function):
         q0 = qkv.data_ptr()
         dqkv = torch.empty_like(qkv)
         g0 = dqkv.data_ptr()
+        Tp = P.shape[-1]
         dP = torch.empty_like(P)
         # dPd = dAtt_h V_h^T
-        _bgemm('nt', datt.data_ptr(), d, T * d, hd, q0 + 2 * d * _F4, 3 * d, T * 3 * d, hd, dP.data_ptr(), T,
-               nh * T * T, T * T, T, T, hd, B, nh, dev)
+        _bgemm('nt', datt.data_ptr(), d, T * d, hd, q0 + 2 * d * _F4, 3 * d, T * 3 * d, hd, dP.data_ptr(), Tp,
+               nh * T * Tp, T * Tp, T, T, hd, B, nh, dev)
         # dV_h = Pd^T dAtt_h
-        _bgemm('tn', Pd.data_ptr(), T, nh * T * T, T * T, datt.data_ptr(), d, T * d, hd, g0 + 2 * d * _F4, 3 * d,
-               T * 3 * d, hd, T, hd, T, B, nh, dev)
+        _bgemm('tn', Pd.data_ptr(), Tp, nh * T * Tp, T * Tp, datt.data_ptr(), d, T * d, hd, g0 + 2 * d * _F4, 3 * d,
+               T * 3 * d, hd, T, hd, T, B, nh, dev, padded=True)
         # dPd -> dS: the dropout mask is re-derived inside the softmax gradient kernel
-        _lib.call('ft_softmax_bwd', P.data_ptr(), dP.data_ptr(), B, nh, T, T, scale, p_drop, seed, H._stream())
+        _lib.call('ft_softmax_bwd', P.data_ptr(), dP.data_ptr(), B, nh, T, T, Tp, scale, p_drop, seed, H._stream())
         # dQ_h = dS K_h ; dK_h = dS^T Q_h
-        _bgemm('nn', dP.data_ptr(), T, nh * T * T, T * T, q0 + d * _F4, 3 * d, T * 3 * d, hd, g0, 3 * d, T * 3 * d, hd,
-               T, hd, T, B, nh, dev)
-        _bgemm('tn', dP.data_ptr(), T, nh * T * T, T * T, q0, 3 * d, T * 3 * d, hd, g0 + d * _F4, 3 * d, T * 3 * d, hd,
-               T, hd, T, B, nh, dev)
+        _bgemm('nn', dP.data_ptr(), Tp, nh * T * Tp, T * Tp, q0 + d * _F4, 3 * d, T * 3 * d, hd, g0, 3 * d, T * 3 * d,
+               hd, T, hd, T, B, nh, dev, padded=True)
+        _bgemm('tn', dP.data_ptr(), Tp, nh * T * Tp, T * Tp, q0, 3 * d, T * 3 * d, hd, g0 + d * _F4, 3 * d, T * 3 * d,
+               hd, T, hd, T, B, nh, dev, padded=True)
         dx = H.linear_bwd_data(dqkv, in_w) if ctx.needs_input_grad[0] else None
         g_iw = _emit(in_w, lambda o: H.linear_bwd_weight_raw(g0, 3 * d, x.data_ptr(), d, o, rows, d, 3 * d), (dqkv, x))
         g_ib = _emit(in_b, lambda o: H.colsum_raw(g0, 3 * d, o, rows, 3 * d), heavy=False)

@@ -122,23 +122,28 @@ int ft_conv1d_bias_fwd(const float* x, long ldx, const float* wp, const float* b
  * instance z -> (z0,z1) = (z/nb1, z%nb1), operand X_z = X + z0*sX0 + z1*sX1 (floats).
  *   nt: C_z[M,N] = A_z[M,K] * B_z[N,K]^T   (scores = Q K^T ; dP = dCtx V^T)
  *   nn: C_z[M,N] = A_z[M,K] * B_z[K,N]     (ctx = P V ; dQ = dS K)
- *   tn: C_z[M,N] = A_z[R,M]^T * B_z[R,N]   (dV = P^T dCtx ; dK = dS^T Q), deterministic split + reduce */
+ *   tn: C_z[M,N] = A_z[R,M]^T * B_z[R,N]   (dV = P^T dCtx ; dK = dS^T Q), deterministic split + reduce
+ * Row padding: attention's [T,T] matrices have a row length (841 frames) that is not a multiple of 4.  The caller keeps
+ * them with a row stride rounded up to 4 and says so -- nn: a_rows_padded = 1 (every row of A readable up to the next
+ * multiple of 4 of K; the values there are ignored), tn: rows_padded = 1 (rows of A / B readable up to the next multiple
+ * of 4 of M / N; those columns only reach masked outputs) -- which keeps these launches on the 16-B-load paths. */
 int ft_bgemm_nt(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
                 long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, void* stream);
 int ft_bgemm_nn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
-                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, void* stream);
+                long ldc, long sC0, long sC1, int M, int N, int K, int nb0, int nb1, int a_rows_padded, void* stream);
 size_t ft_bgemm_tn_workspace(int M, int N, int R, int nb0, int nb1);
 int ft_bgemm_tn(const float* A, long lda, long sA0, long sA1, const float* Bm, long ldb, long sB0, long sB1, float* C,
-                long ldc, long sC0, long sC1, int M, int N, int R, int nb0, int nb1, void* workspace,
+                long ldc, long sC0, long sC1, int M, int N, int R, int nb0, int nb1, int rows_padded, void* workspace,
                 size_t workspace_bytes, void* stream);
-/* scores[B,nh,Tq,Tk] <- softmax(scale*scores + mask) in place; key_pad[B,Tk] bytes (non-zero = padded key) or NULL */
-int ft_softmax_fwd(float* scores, const unsigned char* key_pad, int B, int nh, int Tq, int Tk, float scale,
+/* scores[B,nh,Tq,Tk] (row stride ld >= Tk floats; columns Tk..ld-1 are written as zeros) <- softmax(scale*scores +
+ * mask) in place; key_pad[B,Tk] bytes (non-zero = padded key) or NULL.  dropout_p > 0 also writes dropped =
+ * F.dropout(P, p) (nn.MultiheadAttention's attention dropout; same layout) with ft_dropout's counter-based mask over the
+ * flat LOGICAL [B,nh,Tq,Tk] index, in the same pass. */
+int ft_softmax_fwd(float* scores, const unsigned char* key_pad, int B, int nh, int Tq, int Tk, long ld, float scale,
                    float* dropped, float dropout_p, uint64_t dropout_seed, void* stream);
-/* dprobs <- scale * P * (dprobs' - rowsum(dprobs'*P)) in place; dropout_p > 0: dprobs arrives as the gradient of the
- * DROPPED probabilities and dprobs' = mask * dprobs / (1-p) is formed here (same seed as the forward).
- * Forward: dropout_p > 0 also writes dropped = F.dropout(P, p) (nn.MultiheadAttention's attention dropout) with
- * ft_dropout's counter-based mask over the flat [B,nh,Tq,Tk] index, in the same pass. */
-int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, float scale, float dropout_p,
+/* dprobs <- scale * P * (dprobs' - rowsum(dprobs'*P)) in place (pad columns -> 0); dropout_p > 0: dprobs arrives as the
+ * gradient of the DROPPED probabilities and dprobs' = mask * dprobs / (1-p) is formed here (same seed as the forward) */
+int ft_softmax_bwd(const float* probs, float* dprobs, int B, int nh, int Tq, int Tk, long ld, float scale, float dropout_p,
                    uint64_t dropout_seed, void* stream);
 /* nn.LayerNorm(D) over the last dim with an optional fused residual add: s = x (+res) (stored to sum_out if not
  * NULL), y = LN(s); per-row mean / rstd saved.  bwd: dx (gradient wrt s) and dy_xhat = dy*xhat whose column

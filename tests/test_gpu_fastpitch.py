@@ -47,6 +47,36 @@ def test_strided_batch_gemms(B, nh, T, hd):
     assert torch.isnan(out[..., :d]).all() and torch.isnan(out[..., 2 * d:]).all()      # neighbours untouched
 
 
+@pytest.mark.parametrize('B,nh,T,hd', [(2, 2, 37, 8), (2, 2, 841, 64), (1, 3, 130, 32), (1, 1, 7, 4)])
+def test_row_padded_attention_gemms(B, nh, T, hd):
+    """PV (NN) and P^T dO (TN) with the [T,T] operand stored at a row stride rounded up to 4 and flagged as padded
+    (the aligned 16-B-load paths; T = 841 is the benchmark's frame count): the pad columns hold NaNs here to prove that
+    whatever lies behind column T-1 is ignored (NN) or only reaches masked outputs (TN)."""
+    from forwardtacotron_amd.fastpitch import _bgemm
+    g = torch.Generator().manual_seed(B * 10 + T)
+    d = nh * hd
+    Tp = (T + 3) // 4 * 4
+    qkv = torch.randn(B, T, 3 * d, generator=g)
+    P = torch.randn(B, nh, T, T, generator=g)
+    q = qkv[..., :d].reshape(B, T, nh, hd).permute(0, 2, 1, 3)
+    v = qkv[..., 2 * d:].reshape(B, T, nh, hd).permute(0, 2, 1, 3)
+    Pp = torch.full((B, nh, T, Tp), float('nan'))
+    Pp[..., :T] = P
+    dPp, dq = Pp.cuda(), qkv.cuda()
+    dev = torch.device('cuda')
+    tol = 2e-5 * math.sqrt(max(hd, T))
+    att = torch.full((B, T, d), float('nan'), device='cuda')
+    _bgemm('nn', dPp.data_ptr(), Tp, nh * T * Tp, T * Tp, dq.data_ptr() + 8 * d, 3 * d, T * 3 * d, hd, att.data_ptr(), d,
+           T * d, hd, T, hd, T, B, nh, dev, padded=True)
+    assert maxdiff(att.cpu(), (P @ v).permute(0, 2, 1, 3).reshape(B, T, d)) < tol
+    out = torch.full((B, T, 3 * d), float('nan'), device='cuda')
+    _bgemm('tn', dPp.data_ptr(), Tp, nh * T * Tp, T * Tp, dq.data_ptr(), 3 * d, T * 3 * d, hd, out.data_ptr() + 4 * d,
+           3 * d, T * 3 * d, hd, T, hd, T, B, nh, dev, padded=True)
+    want = (P.transpose(-1, -2) @ q).permute(0, 2, 1, 3).reshape(B, T, d)
+    assert maxdiff(out[..., d:2 * d].cpu(), want) < tol
+    assert torch.isnan(out[..., :d]).all() and torch.isnan(out[..., 2 * d:]).all()
+
+
 @pytest.mark.parametrize('B,T,d,nh,masked', [(3, 9, 16, 2, True), (2, 70, 32, 4, True), (2, 33, 24, 3, False)])
 def test_attention_matches_torch_mha(B, T, d, nh, masked):
     from forwardtacotron_amd.fastpitch import MHAFn
