@@ -178,15 +178,26 @@ class MultiForwardTacotron(nn.Module):
             self.step += 1
             self._bump_batchnorm_counters()
 
-        pitch_cond_hat = self.pitch_cond_pred(x, semb).squeeze(-1)               # [B,Tx,3]
-        dur_hat = self.dur_pred(x, pitch_cond, semb).squeeze(-1)
-        pitch_hat = self.pitch_pred(x, pitch_cond, semb).transpose(1, 2)
-        energy_hat = self.energy_pred(x, semb).transpose(1, 2)
+        # the four predictors are independent of the trunk in training (it consumes the batch's targets,
+        # multi_forward_tacotron.py:183-213) and their 128-step recurrences are latency-bound: side HIP stream,
+        # concurrently with the trunk, as in the single-speaker model (autograd replays each backward node on the
+        # stream of its forward)
+        main = torch.cuda.current_stream()
+        side = self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pitch_cond_hat = self.pitch_cond_pred(x, semb).squeeze(-1)           # [B,Tx,3]
+            dur_hat = self.dur_pred(x, pitch_cond, semb).squeeze(-1)
+            pitch_hat = self.pitch_pred(x, pitch_cond, semb).transpose(1, 2)
+            energy_hat = self.energy_pred(x, semb).transpose(1, 2)
 
         mel_cl, post_cl = self._trunk(x, semb, dur, pitch, energy, mel_lens.to(device=x.device, dtype=torch.long))
         Tout = mel.size(2)
         x_post = ops.TransposePadFn.apply(post_cl, Tout, self.padding_value)
         x_mel = ops.TransposePadFn.apply(mel_cl, Tout, self.padding_value)
+        main.wait_stream(side)
+        for t in (pitch_cond_hat, dur_hat, pitch_hat, energy_hat):
+            t.record_stream(main)
         return {'mel': x_mel, 'mel_post': x_post, 'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat,
                 'pitch_cond': pitch_cond_hat}
 
@@ -212,6 +223,14 @@ class MultiForwardTacotron(nn.Module):
             return {'mel': H.transpose_pad_fwd(mel_cl, T, 0.0), 'mel_post': H.transpose_pad_fwd(post_cl, T, 0.0),
                     'dur': dur_in, 'pitch': pitch_hat, 'energy': energy_hat,
                     'pitch_cond': pitch_cond_hat.unsqueeze(1)}
+
+    def _side_stream(self, device) -> 'torch.cuda.Stream':
+        key = torch.device(device).index or 0
+        if not hasattr(self, '_streams'):
+            self._streams = {}
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
 
     def get_step(self) -> int:
         return self.step.data.item()
