@@ -379,12 +379,21 @@ class FastPitch(nn.Module):
         if self.training:
             self.step += 1
         len_mask = x == 0                                                       # make_token_len_mask
-        dur_hat = self.dur_pred(x, src_pad_mask=len_mask).squeeze(-1)
-        pitch_hat = self.pitch_pred(x, src_pad_mask=len_mask).transpose(1, 2)
-        energy_hat = self.energy_pred(x, src_pad_mask=len_mask).transpose(1, 2)
+        # the three token-side predictors only feed the losses in training (fast_pitch.py:129-131 vs :133-150): side HIP
+        # stream, concurrently with the frame-side trunk (autograd replays their backward on the same stream)
+        main = torch.cuda.current_stream()
+        side = self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dur_hat = self.dur_pred(x, src_pad_mask=len_mask).squeeze(-1)
+            pitch_hat = self.pitch_pred(x, src_pad_mask=len_mask).transpose(1, 2)
+            energy_hat = self.energy_pred(x, src_pad_mask=len_mask).transpose(1, 2)
         mel_cl = self._mel(x, len_mask, dur, batch['pitch'], batch['energy'],
                            mel_lens.to(device=x.device, dtype=torch.long))
         x_mel = ops.TransposePadFn.apply(mel_cl, mel.size(2), self.padding_value)
+        main.wait_stream(side)
+        for t in (dur_hat, pitch_hat, energy_hat):
+            t.record_stream(main)
         return {'mel': x_mel, 'mel_post': x_mel, 'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat}
 
     def generate(self, x: torch.Tensor, alpha=1.0,
@@ -409,6 +418,14 @@ class FastPitch(nn.Module):
     def pad(self, x: torch.Tensor, max_len: int) -> torch.Tensor:
         x = x[:, :, :max_len]
         return torch.nn.functional.pad(x, [0, max_len - x.size(2), 0, 0], 'constant', self.padding_value)
+
+    def _side_stream(self, device) -> 'torch.cuda.Stream':
+        key = torch.device(device).index or 0
+        if not hasattr(self, '_streams'):
+            self._streams = {}
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
 
     def get_step(self) -> int:
         return self.step.data.item()

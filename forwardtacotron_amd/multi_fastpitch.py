@@ -153,13 +153,26 @@ class MultiFastPitch(nn.Module):
         if self.training:
             self.step += 1
         len_mask = x == 0
-        dur_hat = self.dur_pred(x, pitch_cond, semb, src_pad_mask=len_mask).squeeze(-1)
-        pitch_hat = self.pitch_pred(x, pitch_cond, semb, src_pad_mask=len_mask).transpose(1, 2)
-        pitch_cond_hat = self.pitch_cond_pred(x, semb, src_pad_mask=len_mask)
-        energy_hat = self.energy_pred(x, semb, src_pad_mask=len_mask).transpose(1, 2)
+        # predictors on a side HIP stream, concurrently with the frame-side trunk (see FastPitch.forward)
+        main = torch.cuda.current_stream()
+        key = x.device.index or 0
+        if not hasattr(self, '_streams'):
+            self._streams = {}
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=x.device)
+        side = self._streams[key]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dur_hat = self.dur_pred(x, pitch_cond, semb, src_pad_mask=len_mask).squeeze(-1)
+            pitch_hat = self.pitch_pred(x, pitch_cond, semb, src_pad_mask=len_mask).transpose(1, 2)
+            pitch_cond_hat = self.pitch_cond_pred(x, semb, src_pad_mask=len_mask)
+            energy_hat = self.energy_pred(x, semb, src_pad_mask=len_mask).transpose(1, 2)
         mel_cl = self._mel(x, semb, len_mask, dur, batch['pitch'], batch['energy'],
                            mel_lens.to(device=x.device, dtype=torch.long))
         x_mel = ops.TransposePadFn.apply(mel_cl, mel.size(2), self.padding_value)
+        main.wait_stream(side)
+        for t in (dur_hat, pitch_hat, pitch_cond_hat, energy_hat):
+            t.record_stream(main)
         return {'mel': x_mel, 'mel_post': x_mel, 'pitch_cond': pitch_cond_hat, 'dur': dur_hat, 'pitch': pitch_hat,
                 'energy': energy_hat}
 
