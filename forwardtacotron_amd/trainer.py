@@ -9,6 +9,7 @@ group the flat gradient is sum-all-reduced in buckets overlapped with backward (
 1/world factor is folded into the clip coefficient.  BatchNorm statistics stay per rank (the reference has
 no SyncBN), every rank applies the identical Adam update.
 """
+import os
 from typing import Dict, Optional
 
 import torch
@@ -48,6 +49,8 @@ class TrainStep:
         self.sink = ops.GradSink({p.data_ptr(): (i, p.grad) for i, p in enumerate(self.flat.params)},
                                  stream=self.wgrad_stream, on_write=self.reducer.notify)
         self.packs: Optional[H.PackCache] = None
+        self.main_stream = (torch.cuda.Stream(device=dev, priority=-1)
+                            if os.environ.get('FT_MAIN_PRIORITY', '1') == '1' else None)
         self._packs_base = 0
 
     def _weight_packs(self) -> H.PackCache:
@@ -93,6 +96,21 @@ class TrainStep:
         """batch: device tensors with the ForwardCollator layout (utils/dataset.py:239-263).  Returns the
         loss terms and the pre-clip gradient norm as device scalars (no host sync in here except the
         LengthRegulator's output-size read, which the reference has too)."""
+        if self.main_stream is None:
+            return self._step(batch)
+        # the step's critical path runs on a HIGH-priority stream: its bandwidth-bound kernels (BatchNorm statistics,
+        # pooling gradients) otherwise queue behind the side stream's weight-gradient GEMMs, whose workgroups fill the
+        # register files of every CU
+        cur = torch.cuda.current_stream()
+        self.main_stream.wait_stream(cur)
+        with torch.cuda.stream(self.main_stream):
+            out = self._step(batch)
+        cur.wait_stream(self.main_stream)
+        for v in out.values():
+            v.record_stream(cur)
+        return out
+
+    def _step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         model = self.model
         model.train()
         if not self.flat.attached():
