@@ -328,6 +328,7 @@ class ForwardTacotron(nn.Module):
         # token-side row count (incl. the conv bank's extra row): trainer.TrainStep keeps weight gradients of
         # operands this short on the main stream (ops.GradSink.inline_rows)
         self.wgrad_inline_rows = x.shape[0] * (x.shape[1] + 1)
+        self.wgrad_defer = True          # recurrences ahead: ops.GradSink.defer
         if self.training:
             self.step += 1
             self._bump_batchnorm_counters()

@@ -41,9 +41,17 @@ class GradSink:
         # (1.9 ms of a 28.4 ms step); on the main stream the two tails overlap.  FastPitch, whose whole token side
         # is launch-bound, is faster with everything on the side stream and leaves it at 0.
         self.inline_rows = 0
+        # defer = True: side-stream weight gradients are not launched where they are emitted but queued, and launched
+        # in one go right before the next recurrence's BPTT kernel (ops.flush_deferred) -- the persistent recurrences
+        # leave most of the chip idle, while between them the main stream's own GEMM / BatchNorm chain wants it all
+        self.defer = False
+        self.pending = []               # (compute, views, deps, indices)
+        self.held = set()               # indices queued in `pending`: claimed, not yet issued (the all-reduce must wait)
 
     def begin_step(self):
         self.written.clear()
+        self.pending.clear()
+        self.held.clear()
 
 
 _SINK: Optional[GradSink] = None
@@ -71,6 +79,44 @@ def _sink_done(idx: int) -> None:
         _SINK.on_write(idx)
 
 
+def _side_launch(compute, views, deps, idxs) -> None:
+    """run compute(views) on the sink's side stream now, or queue it (GradSink.defer)"""
+    if _SINK.defer:
+        for i in idxs:
+            _SINK.written.add(i)        # the slot is taken; the reducer hears about it when the launch is issued
+            _SINK.held.add(i)
+        _SINK.pending.append((compute, views, deps, idxs))
+        return
+    side = _SINK.stream
+    side.wait_stream(torch.cuda.current_stream())
+    for t in deps:                      # keep the operands' memory from being recycled under the side stream
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        compute(views)
+    for i in idxs:
+        _sink_done(i)
+
+
+def flush_deferred() -> None:
+    """issue every queued side-stream weight gradient (no-op without a deferring sink)"""
+    sink = _SINK
+    if sink is None or not sink.pending:
+        return
+    side = sink.stream
+    side.wait_stream(torch.cuda.current_stream())
+    pend, sink.pending = sink.pending, []
+    with torch.cuda.stream(side):
+        for compute, views, deps, idxs in pend:
+            for t in deps:
+                t.record_stream(side)
+            compute(views)
+    for _, _, _, idxs in pend:
+        for i in idxs:
+            sink.held.discard(i)
+            if sink.on_write is not None:
+                sink.on_write(i)
+
+
 def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
     """Produces the gradient of parameter `w`: compute(out) must overwrite `out` (same shape as w).
     Without a sink: returns a fresh tensor (autograd accumulates it).  With a sink: writes the flat-buffer
@@ -86,14 +132,9 @@ def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
         side = None                     # short (token-side) operands: see GradSink.inline_rows
     if side is None:
         compute(view)
+        _sink_done(idx)
     else:
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        for t in deps:                  # keep the operands' memory from being recycled under the side stream
-            t.record_stream(side)
-        with torch.cuda.stream(side):
-            compute(view)
-    _sink_done(idx)
+        _side_launch(compute, view, deps, (idx,))
     return None
 
 
@@ -110,15 +151,10 @@ def _emit_multi(ws, compute, deps=(), heavy: bool = True):
     views = [e[1] for e in ents]
     if side is None:
         compute(views)
+        for e in ents:
+            _sink_done(e[0])
     else:
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        for t in deps:
-            t.record_stream(side)
-        with torch.cuda.stream(side):
-            compute(views)
-    for e in ents:
-        _sink_done(e[0])
+        _side_launch(compute, views, deps, tuple(e[0] for e in ents))
     return [None] * len(ws)
 
 
@@ -406,6 +442,7 @@ class BiGRUFn(Function):
         x, out, gates = ctx.saved_tensors[:3]
         params = ctx.saved_tensors[3:]
         Hh = ctx.Hh
+        flush_deferred()        # queued weight gradients run beside the recurrence
         dxp, dhp = H.gru_bwd(_c(dout), out, gates, H.transpose2d(params[1]), H.transpose2d(params[5]), Hh)
         dx, g = _rnn_param_grads(dxp, dhp, x, out, 3, Hh, params, ctx.needs_input_grad[0])
         return (dx, *g)
@@ -435,6 +472,7 @@ class BiLSTMFn(Function):
         x, raw, cst, gates, lens = ctx.saved_tensors[:5]
         params = ctx.saved_tensors[5:]
         Hh = ctx.Hh
+        flush_deferred()
         dg = H.lstm_bwd(H.bt_transpose(_c(dout), True), raw, cst, gates, H.transpose2d(params[1]),
                         H.transpose2d(params[5]), lens if ctx.has_lens else None, Hh)
         dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, params, ctx.needs_input_grad[0])

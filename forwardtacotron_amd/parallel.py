@@ -115,6 +115,7 @@ class BucketedAllReduce:
         self.armed = False
         self.streams = set()
         self.seen = set()
+        self.held = None                # set of parameter indices a gradient sink still owes (ops.GradSink.held)
         self.comm_stream = None
         if self.world > 1:
             for j, p in enumerate(flat.params):
@@ -122,6 +123,10 @@ class BucketedAllReduce:
 
     def _make_hook(self, j: int):
         def hook(p):
+            # a gradient sink that has claimed this parameter announces it itself, when its kernel is really issued
+            # (deferred weight gradients are issued later than autograd visits the leaf)
+            if self.held is not None and j in self.held:
+                return
             self.notify(j)
         return hook
 

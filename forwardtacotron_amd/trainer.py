@@ -48,6 +48,7 @@ class TrainStep:
         self.reducer.streams.add(self.wgrad_stream)
         self.sink = ops.GradSink({p.data_ptr(): (i, p.grad) for i, p in enumerate(self.flat.params)},
                                  stream=self.wgrad_stream, on_write=self.reducer.notify)
+        self.reducer.held = self.sink.held
         self.packs: Optional[H.PackCache] = None
         self.main_stream = (torch.cuda.Stream(device=dev, priority=-1)
                             if os.environ.get('FT_MAIN_PRIORITY', '1') == '1' else None)
@@ -135,9 +136,12 @@ class TrainStep:
             self.reducer.start()
             self.sink.begin_step()
             self.sink.inline_rows = int(getattr(model, 'wgrad_inline_rows', 0))
+            # models with recurrences queue their side-stream weight gradients and issue them beside the next BPTT kernel
+            self.sink.defer = bool(getattr(model, 'wgrad_defer', False)) and os.environ.get('FT_WGRAD_DEFER', '1') == '1'
             ops.set_grad_sink(self.sink)
             try:
                 L['loss'].backward()
+                ops.flush_deferred()
             finally:
                 ops.set_grad_sink(None)
         finally:
