@@ -45,7 +45,7 @@ class GradSink:
         # in one go right before the next recurrence's BPTT kernel (ops.flush_deferred) -- the persistent recurrences
         # leave most of the chip idle, while between them the main stream's own GEMM / BatchNorm chain wants it all
         self.defer = False
-        self.pending = []               # (compute, views, deps, indices)
+        self.pending = []               # (compute, views, deps, indices, ready event)
         self.held = set()               # indices queued in `pending`: claimed, not yet issued (the all-reduce must wait)
 
     def begin_step(self):
@@ -85,7 +85,12 @@ def _side_launch(compute, views, deps, idxs) -> None:
         for i in idxs:
             _SINK.written.add(i)        # the slot is taken; the reducer hears about it when the launch is issued
             _SINK.held.add(i)
-        _SINK.pending.append((compute, views, deps, idxs))
+        # the operands are complete once the EMITTING stream gets here: the flush may run on another stream (a
+        # predictor's recurrence on its side stream flushes gradients the main stream emitted), so each item carries
+        # its own event
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+        _SINK.pending.append((compute, views, deps, idxs, ready))
         return
     side = _SINK.stream
     side.wait_stream(torch.cuda.current_stream())
@@ -103,14 +108,14 @@ def flush_deferred() -> None:
     if sink is None or not sink.pending:
         return
     side = sink.stream
-    side.wait_stream(torch.cuda.current_stream())
     pend, sink.pending = sink.pending, []
     with torch.cuda.stream(side):
-        for compute, views, deps, idxs in pend:
+        for compute, views, deps, idxs, ready in pend:
+            side.wait_event(ready)
             for t in deps:
                 t.record_stream(side)
             compute(views)
-    for _, _, _, idxs in pend:
+    for _, _, _, idxs, _ in pend:
         for i in idxs:
             sink.held.discard(i)
             if sink.on_write is not None:

@@ -117,3 +117,34 @@ def test_mid_size_train_step_vs_oracle():
                     if d > worst:
                         worst, worst_k = d, k
     assert worst < 1e-4, (worst, worst_k)
+
+
+def test_deferred_weight_gradients_wait_for_the_emitting_stream():
+    """A queued (GradSink.defer) weight gradient may be flushed from ANOTHER stream than the one that emitted it (a
+    predictor's recurrence on its side stream flushes what the main stream queued): the side stream must then wait for
+    the EMITTING stream's position, not the flusher's.  Stream A is held up by a long spin before it produces the
+    operand; the flush comes from an idle stream B right away."""
+    from forwardtacotron_amd import ops
+    dev = torch.device('cuda')
+    w = torch.zeros(1 << 20, device=dev)
+    view = torch.full_like(w, -1.0)
+    src = torch.zeros_like(w)
+    A, B_, side = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    sink = ops.GradSink({w.data_ptr(): (0, view)}, stream=side)
+    sink.defer = True
+    sink.begin_step()
+    ops.set_grad_sink(sink)
+    try:
+        torch.cuda.synchronize()
+        with torch.cuda.stream(A):
+            torch.cuda._sleep(200_000_000)                  # ~0.1 s: the operand is NOT ready for a long time
+            src.fill_(3.0)
+            r = ops._emit(w, lambda out: out.copy_(src), (src.view(1024, -1),))
+            assert r is None and sink.pending and 0 in sink.held
+        with torch.cuda.stream(B_):
+            ops.flush_deferred()
+        assert not sink.pending and not sink.held
+        torch.cuda.synchronize()
+        assert float(view.min()) == 3.0 and float(view.max()) == 3.0
+    finally:
+        ops.set_grad_sink(None)
