@@ -47,11 +47,15 @@ class GradSink:
         self.defer = False
         self.pending = []               # (compute, views, deps, indices, ready event)
         self.held = set()               # indices queued in `pending`: claimed, not yet issued (the all-reduce must wait)
+        self.main = None
+        self.used = set()               # streams gradient writes were issued on this step
 
     def begin_step(self):
         self.written.clear()
         self.pending.clear()
         self.held.clear()
+        self.used.clear()
+        self.main = torch.cuda.current_stream() if torch.cuda.is_available() else None   # the step's critical stream
 
 
 _SINK: Optional[GradSink] = None
@@ -75,6 +79,10 @@ def _sink_view(w: torch.Tensor):
 
 def _sink_done(idx: int) -> None:
     _SINK.written.add(idx)
+    # The write was just issued on (or handed over from) the current stream.  Autograd only joins the streams on which
+    # it accumulated a leaf gradient itself, and the sink's parameters never get there, so whoever applies the
+    # gradients must wait for every stream recorded here (a predictor's backward runs on the predictor side stream).
+    _SINK.used.add(torch.cuda.current_stream())
     if _SINK.on_write is not None:
         _SINK.on_write(idx)
 
@@ -85,11 +93,15 @@ def _side_launch(compute, views, deps, idxs) -> None:
         for i in idxs:
             _SINK.written.add(i)        # the slot is taken; the reducer hears about it when the launch is issued
             _SINK.held.add(i)
-        # the operands are complete once the EMITTING stream gets here: the flush may run on another stream (a
-        # predictor's recurrence on its side stream flushes gradients the main stream emitted), so each item carries
-        # its own event
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream())
+        # The operands are complete once the EMITTING stream gets here, and the flush may run on another stream (a
+        # predictor's recurrence on its side stream flushes gradients the main stream emitted).  Items emitted on the
+        # step's main stream carry no event -- an event record costs the critical stream tens of microseconds, and the
+        # flush simply waits for that stream's position at flush time -- items from any other stream carry their own.
+        cur = torch.cuda.current_stream()
+        ready = None
+        if _SINK.main is None or cur != _SINK.main:
+            ready = torch.cuda.Event()
+            ready.record(cur)
         _SINK.pending.append((compute, views, deps, idxs, ready))
         return
     side = _SINK.stream
@@ -109,9 +121,12 @@ def flush_deferred() -> None:
         return
     side = sink.stream
     pend, sink.pending = sink.pending, []
+    if any(ready is None for _, _, _, _, ready in pend):
+        side.wait_stream(sink.main)     # one record for everything the main stream emitted since the last flush
     with torch.cuda.stream(side):
         for compute, views, deps, idxs, ready in pend:
-            side.wait_event(ready)
+            if ready is not None:
+                side.wait_event(ready)
             for t in deps:
                 t.record_stream(side)
             compute(views)

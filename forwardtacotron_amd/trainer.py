@@ -146,7 +146,11 @@ class TrainStep:
                 ops.set_grad_sink(None)
         finally:
             H.pack_cache = None
-        torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.wgrad_stream)
+        for st in self.sink.used:               # e.g. the predictors' side stream: its backward wrote gradients too
+            if st != cur and st != self.wgrad_stream:
+                cur.wait_stream(st)
         self.reducer.finish()
         self.optimizer_step()
         out = {k: v.detach() for k, v in L.items()}
