@@ -115,19 +115,31 @@ def _side_launch(compute, views, deps, idxs) -> None:
         _sink_done(i)
 
 
-def flush_deferred() -> None:
-    """issue every queued side-stream weight gradient (no-op without a deferring sink)"""
+def flush_begin():
+    """First half of a flush: joins the side stream with the emitting streams NOW (so that it does not wait for whatever
+    the caller launches next) and hands back the queued launches; flush_end issues them.  A recurrence's backward calls
+    flush_begin, launches its BPTT kernel, then flush_end: the persistent kernel (all of whose workgroups must become
+    co-resident) is dispatched before the GEMMs that would otherwise fill every CU's registers first."""
     sink = _SINK
     if sink is None or not sink.pending:
-        return
+        return None
     side = sink.stream
     pend, sink.pending = sink.pending, []
     if any(ready is None for _, _, _, _, ready in pend):
         side.wait_stream(sink.main)     # one record for everything the main stream emitted since the last flush
+    for _, _, _, _, ready in pend:
+        if ready is not None:
+            side.wait_event(ready)
+    return pend
+
+
+def flush_end(pend) -> None:
+    if not pend:
+        return
+    sink = _SINK
+    side = sink.stream
     with torch.cuda.stream(side):
-        for compute, views, deps, idxs, ready in pend:
-            if ready is not None:
-                side.wait_event(ready)
+        for compute, views, deps, idxs, _ in pend:
             for t in deps:
                 t.record_stream(side)
             compute(views)
@@ -136,6 +148,11 @@ def flush_deferred() -> None:
             sink.held.discard(i)
             if sink.on_write is not None:
                 sink.on_write(i)
+
+
+def flush_deferred() -> None:
+    """issue every queued side-stream weight gradient (no-op without a deferring sink)"""
+    flush_end(flush_begin())
 
 
 def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
@@ -463,8 +480,9 @@ class BiGRUFn(Function):
         x, out, gates = ctx.saved_tensors[:3]
         params = ctx.saved_tensors[3:]
         Hh = ctx.Hh
-        flush_deferred()        # queued weight gradients run beside the recurrence
+        pend = flush_begin()    # queued weight gradients run beside the recurrence, issued right behind its launch
         dxp, dhp = H.gru_bwd(_c(dout), out, gates, H.transpose2d(params[1]), H.transpose2d(params[5]), Hh)
+        flush_end(pend)
         dx, g = _rnn_param_grads(dxp, dhp, x, out, 3, Hh, params, ctx.needs_input_grad[0])
         return (dx, *g)
 
@@ -493,9 +511,11 @@ class BiLSTMFn(Function):
         x, raw, cst, gates, lens = ctx.saved_tensors[:5]
         params = ctx.saved_tensors[5:]
         Hh = ctx.Hh
-        flush_deferred()
-        dg = H.lstm_bwd(H.bt_transpose(_c(dout), True), raw, cst, gates, H.transpose2d(params[1]),
+        dout_tm = H.bt_transpose(_c(dout), True)
+        pend = flush_begin()
+        dg = H.lstm_bwd(dout_tm, raw, cst, gates, H.transpose2d(params[1]),
                         H.transpose2d(params[5]), lens if ctx.has_lens else None, Hh)
+        flush_end(pend)
         dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, params, ctx.needs_input_grad[0])
         return (dx, None, None, *g)
 
