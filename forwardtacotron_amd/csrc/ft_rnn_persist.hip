@@ -75,6 +75,7 @@ __device__ __forceinline__ float4 as_f4(const u32x4& v) {
 struct Geom {
   int nchunks, nbg, total;             // chunks per group, batch groups, workgroups that have work
   int xcd_aware, sig_per_wave;
+  int xcd_off;                         // group-aligned placement: physical XCD of logical slot 0
 };
 
 __device__ __forceinline__ float4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -104,7 +105,7 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned step
 // [x*per, (x+1)*per).  Only locality depends on that; any placement is correct.
 __device__ __forceinline__ bool decode(const Geom& g, int& d, int& bgp, int& chunk, int& grp) {
   const int lin = blockIdx.x, per = gridDim.x >> 3;
-  const int w = g.xcd_aware ? (lin & 7) * per + (lin >> 3) : lin;
+  const int w = g.xcd_aware ? (((lin & 7) + 8 - g.xcd_off) & 7) * per + (lin >> 3) : lin;
   if (w >= g.total) return false;
   grp = w / g.nchunks;
   chunk = w - grp * g.nchunks;
@@ -787,6 +788,29 @@ PersistWs carve_ws_rs(void* ws, int ngrp, int nchunks) {
   return p;
 }
 
+// 1-D grid = 8 x (work items per XCD): the decode hands XCD x the items [x*per, (x+1)*per).  Small layers (<= 64
+// workgroups, whole (direction, batch group) groups of <= 32 workgroups: the postnet's GRU-128, the predictors' GRU-64)
+// get per rounded up to whole groups, so that a group's hand-off stays inside ONE XCD (GRU-128: 2.49 -> 2.06 / 2.95 -> 2.50
+// us per step fwd / bwd); the surplus workgroups of the larger grid exit at once, and successive launches start on
+// different XCDs so that concurrent small recurrences (predictors beside the prenet) do not pile onto the same ones.
+// Larger layers keep the spread mapping: pinned to half of the XCDs they would have to wait for the CUs that the
+// weight-gradient GEMMs running beside them hold (measured in-step: +1.7 ms).
+int persist_grid(Geom& geo) {
+  static int rotor = 0;
+  int per = ft_cdiv(geo.total, 8);
+  geo.xcd_off = 0;
+  if (geo.xcd_aware && env_int("FT_RNN_XCDALIGN", 1) && geo.total <= 64 && geo.nchunks <= 32) {
+    const int ngroups = geo.total / geo.nchunks;
+    const int aligned = geo.nchunks * ft_cdiv(ngroups, 8);
+    if (aligned <= 32) {
+      per = aligned;
+      geo.xcd_off = rotor & 7;
+      rotor += ngroups < 8 ? ngroups : 8;
+    }
+  }
+  return 8 * per;
+}
+
 template <typename KernelT>
 bool grid_fits(KernelT kernel, int block, long nblocks) {
   int per_cu = 0;
@@ -820,7 +844,7 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
   PersistWs p = carve_ws(ws, 2 * geo.nbg, H);
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
-  const int grid = 8 * ft_cdiv(geo.total, 8);
+  const int grid = persist_grid(geo);
   a.s = 0;
   if (H % 32 == 0 && ft_cdiv(H / 32, NW) <= GCH / 2 && env_int("FT_RNN_B3", 1))     // matmul on the bf16 pipe (exact split)
     return NW == 8 ? launch_fwd_persist<G, 8, true>(a, geo, p, grid, stream)
@@ -886,7 +910,7 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.total = 2 * geo.nbg * geo.nchunks;
   geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
   geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
-  const int grid = 8 * ft_cdiv(geo.total, 8);
+  const int grid = persist_grid(geo);
   a.s = 0;
   {
     const int rc = bwd_persistent_rs<G>(a, geo, ws, ws_bytes, grid, stream);
