@@ -11,7 +11,7 @@
 // AGPR/VGPR), BK = 32 per stage.  LDS tiles are K-major ([k][m]) so the MFMA operand fetch
 // (lane l: row l&31, k = kk + (l>>5)) is a conflict-free ds_read_b32 across 32 consecutive floats.
 // Measured ceiling of this tiling as a plain GEMM: 105-113 TFLOP/s of the 157 the f32 MFMA pipe offers
-// (scratch/gemm_lab.hip: operands in registers only 133-143, + LDS fetch 127-134, + LDS stores 120-130, + global
+// (lab/gemm_lab.hip: operands in registers only 133-143, + LDS fetch 127-134, + LDS stores 120-130, + global
 // loads 105-113); these kernels reach 87-102 with row maps, taps and fused epilogues.  The 128x128 NT launches are
 // routed to the bf16-split kernel of ft_gemm_b3.hip instead (136-148 TFLOP/s fp32-equivalent); this file keeps the
 // 64x64 tiles, the [K][N] operand form, unaligned / odd shapes and the TN (weight-gradient) kernel.
@@ -551,7 +551,7 @@ TNPlan plan_tn(const FtGemmTNTask& t, bool b3_ok) {
     const long live = tiles * (K + 1) / (2 * K);
     want = (2048 + live - 1) / (live > 0 ? live : 1);
   }
-  static const long force_s = [] {             // FT_TN_FORCE_S=<n>: tuning aid (scratch/tn_split_lab.py)
+  static const long force_s = [] {             // FT_TN_FORCE_S=<n>: tuning aid (lab/tn_split_lab.py)
     const char* e = getenv("FT_TN_FORCE_S");
     return e ? atol(e) : 0L;
   }();

@@ -4,7 +4,7 @@
 // and a product keeps the six terms down to 2^-16 relative (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi), accumulated
 // in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are <= 2^-23 |a||b| -- the size of fp32's own product
 // rounding: measured against an f64 reference the result is as close as (slightly closer than) the
-// v_mfma_f32_32x32x2_f32 path (scratch/gemm_lab_b3.h: 1.9e-5 vs 2.3e-5 max error at K = 512, |C| up to 26).
+// v_mfma_f32_32x32x2_f32 path (lab/gemm_lab_b3.h: 1.9e-5 vs 2.3e-5 max error at K = 512, |C| up to 26).
 // bf16 MFMA runs at 16x the fp32 MFMA rate and six of them replace one, so the matrix pipe has 2.67x fewer cycles to
 // spend; what bounds the kernel instead is the staging work (split = ~5 VALU ops per element, LDS traffic).
 //

@@ -879,7 +879,7 @@ int bwd_persistent_rs(RnnBwdArgs a, const Geom& geo, void* ws, size_t ws_bytes, 
   if (!env_int("FT_RNN_BWD_RS", 1) || !env_int("FT_RNN_B3", 1) || !geo.sig_per_wave) return -1;
   PersistWs p = carve_ws_rs(ws, 2 * geo.nbg, geo.nchunks);
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
-  // measured (scratch/rnn_step_us.py, B = 32, us/step, all-gather -> reduce-scatter): LSTM H=512 5.26 -> 4.67;
+  // measured (lab/rnn_step_us.py, B = 32, us/step, all-gather -> reduce-scatter): LSTM H=512 5.26 -> 4.67;
   // GRU H=256 3.15 -> 3.60, H=128 2.87 -> 2.95, H=64 2.70 -> 2.73: the form pays once the gathered operand is large
   // (G*H >= 1024 values per row); FT_RNN_BWD_RS=2 forces it wherever it applies
   const bool force = env_int("FT_RNN_BWD_RS", 1) == 2;

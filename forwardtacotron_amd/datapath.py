@@ -93,34 +93,55 @@ class ForwardCollator:
         return output
 
 
+def _drawn_permutation(n: int) -> np.ndarray:
+    """A permutation of range(n) drawn from python's global `random` with exactly the draws `random.shuffle` makes on
+    a sequence of length n (the draws depend on the length only): shuffling x in place equals x[_drawn_permutation(n)]."""
+    order = list(range(n))
+    random.shuffle(order)
+    return np.asarray(order, dtype=np.int64)
+
+
 class BinnedLengthSampler(torch.utils.data.Sampler):
-    """utils/dataset.py:54-83: indices sorted by length, shuffled inside bins of `bin_size`, bins shuffled, the
-    remainder shuffled and appended.  Driven by python's `random` exactly like the reference (same seed -> same
-    order); batches drawn from it are length-homogeneous, which is what keeps the padded GEMM shapes tight."""
+    """Length-binned epoch order with the reference's semantics (utils/dataset.py:54-83), written as permutations:
+
+        ranks   = item indices in ascending length order                       (torch.sort, as the reference)
+        table   = the first n_bins * bin_size ranks as a [n_bins, bin_size] table, tail = the rest
+        epoch   = every table row permuted (row 0 first), then the ROWS permuted, then the tail permuted, concatenated
+
+    Each permutation consumes python's global `random` stream exactly like one `random.shuffle` of that length, in
+    that order, so the same `random.seed` gives the reference's epoch (tests/golden/sampler.npz holds orders captured
+    from the reference class).  Like the reference -- which shuffles views of its own index array -- the within-row and
+    tail permutations PERSIST in the object from one epoch to the next (the row permutation does not); a DataLoader
+    that re-iterates one sampler therefore sees the reference's second epoch too.  Batches cut from an epoch are
+    length-homogeneous, which keeps the padded GEMM shapes of a step tight.
+
+    Deliberate difference: with fewer items than one bin the reference fails inside np.stack([]) (ValueError); here
+    such a dataset is just its permuted tail."""
 
     def __init__(self, lengths, batch_size: int, bin_size: int):
-        _, self.idx = torch.sort(torch.tensor(lengths).long())
-        self.batch_size = batch_size
-        self.bin_size = bin_size
-        assert self.bin_size % self.batch_size == 0
+        if bin_size % batch_size != 0:
+            raise AssertionError('bin_size must be a multiple of batch_size')
+        self.batch_size, self.bin_size = batch_size, bin_size
+        ranks = torch.sort(torch.tensor(lengths).long())[1].numpy().copy()
+        n_bins = len(ranks) // bin_size
+        self._table = ranks[:n_bins * bin_size].reshape(n_bins, bin_size)
+        self._tail = ranks[n_bins * bin_size:]
 
     def __iter__(self):
-        idx = self.idx.numpy()
-        bins = []
-        for i in range(len(idx) // self.bin_size):
-            this_bin = idx[i * self.bin_size:(i + 1) * self.bin_size]
-            random.shuffle(this_bin)
-            bins += [this_bin]
-        random.shuffle(bins)
-        binned_idx = np.stack(bins).reshape(-1) if bins else np.empty(0, dtype=idx.dtype)
-        if len(binned_idx) < len(idx):
-            last_bin = idx[len(binned_idx):]
-            random.shuffle(last_bin)
-            binned_idx = np.concatenate([binned_idx, last_bin])
-        return iter(torch.tensor(binned_idx).long())
+        table, tail = self._table, self._tail
+        for r in range(table.shape[0]):
+            table[r] = table[r][_drawn_permutation(table.shape[1])]
+        parts = []
+        if table.shape[0]:
+            parts.append(table[_drawn_permutation(table.shape[0])].reshape(-1))
+        if len(tail):
+            tail[:] = tail[_drawn_permutation(len(tail))]
+            parts.append(tail)
+        epoch = np.concatenate(parts) if parts else np.empty(0, dtype=np.int64)
+        return iter(torch.from_numpy(epoch.astype(np.int64, copy=True)))
 
     def __len__(self):
-        return len(self.idx)
+        return self._table.size + len(self._tail)
 
 
 class DevicePrefetcher:

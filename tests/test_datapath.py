@@ -1,7 +1,8 @@
 """Data path.  The collator checks restate the reference's own tests/test_collator.py:40-65 (same
-items, same expected values); the sampler is checked through the properties its algorithm guarantees
-(utils/dataset.py:54-83 -- not importable here: it needs librosa), incl. that it consumes python's `random` stream
-the way the reference does (same seed -> same order as an independent transcription of the algorithm)."""
+items, same expected values); the sampler is checked against index
+orders captured from the reference's class (tests/golden/sampler.npz, made by tests/golden/make_golden_sampler.py) and
+through the properties its algorithm guarantees (utils/dataset.py:54-83)."""
+import os
 import random
 
 import numpy as np
@@ -54,43 +55,46 @@ def test_collate_reduction_factor_and_cut():
     assert TacoCollator(r=1)(f32)['mel'].dtype == torch.float32
 
 
-def _reference_order(lengths, bin_size):
-    """Independent transcription of utils/dataset.py:62-80 for the expected order."""
-    idx = np.argsort(np.asarray(lengths), kind='stable')
-    idx = torch.sort(torch.tensor(lengths).long())[1].numpy()
-    bins = []
-    for i in range(len(idx) // bin_size):
-        b = idx[i * bin_size:(i + 1) * bin_size]
-        random.shuffle(b)
-        bins.append(b)
-    random.shuffle(bins)
-    out = np.stack(bins).reshape(-1)
-    if len(out) < len(idx):
-        last = idx[len(out):]
-        random.shuffle(last)
-        out = np.concatenate([out, last])
-    return out.tolist()
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sampler.npz')
 
 
-def test_binned_length_sampler():
+def test_binned_length_sampler_matches_reference_orders():
+    """orders captured from the reference class by tests/golden/make_golden_sampler.py (incl. the second epoch of
+    one sampler object, whose start state the reference's in-place shuffles leave behind)"""
+    g = np.load(GOLD)
+    seen = 0
+    for c in range(int(g['n_cases'])):
+        lengths = g[f'c{c}_lengths'].tolist()
+        bs, bin_size, rseed = (int(v) for v in g[f'c{c}_cfg'])
+        s = BinnedLengthSampler(lengths, batch_size=bs, bin_size=bin_size)
+        assert len(s) == len(lengths)
+        random.seed(rseed)
+        if int(g[f'c{c}_raises']):
+            # fewer items than a bin: the reference dies in np.stack([]); here the epoch is the permuted tail
+            assert sorted(int(i) for i in s) == list(range(len(lengths)))
+            continue
+        assert [int(i) for i in s] == g[f'c{c}_order'].tolist()
+        assert [int(i) for i in s] == g[f'c{c}_order2'].tolist()
+        seen += 1
+    assert seen >= 4
+
+
+def test_binned_length_sampler_properties():
     g = np.random.RandomState(0)
     lengths = g.randint(10, 900, size=103).tolist()
     s = BinnedLengthSampler(lengths, batch_size=4, bin_size=12)
     random.seed(7)
     order = [int(i) for i in s]
     assert len(s) == 103 and sorted(order) == list(range(103))           # a permutation
-    random.seed(7)
-    assert order == _reference_order(lengths, 12)                          # same use of the `random` stream
-    srt = np.argsort(np.asarray(lengths), kind='stable')
     rank = {int(i): r for r, i in enumerate(torch.sort(torch.tensor(lengths).long())[1].tolist())}
     # every full bin is a contiguous range of the length-sorted order; the remainder (7 longest) comes last
     for b in range(103 // 12):
         ranks = sorted(rank[i] for i in order[b * 12:(b + 1) * 12])
         assert ranks == list(range(ranks[0], ranks[0] + 12)) and ranks[0] % 12 == 0
     assert sorted(rank[i] for i in order[96:]) == list(range(96, 103))
-    assert len(srt) == 103
     with pytest.raises(AssertionError):
         BinnedLengthSampler(lengths, batch_size=5, bin_size=12)
+    assert [int(i) for i in BinnedLengthSampler([], 2, 4)] == []
 
 
 def _dataset(n=20, seed=3):
