@@ -21,6 +21,9 @@ int ft_check_launch(const char* what);
     }                                    \
   } while (0)
 
+// device address of the current device's sticky recurrence-fault word (ft_rnn_persist.hip); read by the optimizer kernels
+unsigned* ft_rnn_fault_word();
+
 static inline int ft_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // accurate (ocml) forms: the recurrences run 841 dependent steps and must hold 1e-4 abs

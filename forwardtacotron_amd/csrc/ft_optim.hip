@@ -27,8 +27,12 @@ __global__ __launch_bounds__(256) void ft_sumsq_partial_kernel(const float* __re
 }
 
 // norm = sqrt(sum)*pre_scale ; coef = pre_scale * min(1, max_norm / (norm + 1e-6))   (max_norm <= 0: no clipping)
+// fault: the device's sticky recurrence-fault word (ft_rnn_persist.hip).  If a persistent recurrence timed out since the
+// word was last cleared, the gradients of this step are garbage: out[2] = 1 makes ft_adam_kernel skip the update, the
+// coefficient is 0 and the reported norm NaN, so that nothing downstream can mistake the step for a valid one.
 __global__ __launch_bounds__(256) void ft_clip_coef_kernel(const double* __restrict__ partial, int nblocks,
                                                            float max_norm, float pre_scale,
+                                                           const unsigned* __restrict__ fault,
                                                            float* __restrict__ out) {
   __shared__ double red[4];
   double s = 0.0;
@@ -44,8 +48,11 @@ __global__ __launch_bounds__(256) void ft_clip_coef_kernel(const double* __restr
     c = max_norm / (norm + 1e-6f);
     if (c > 1.0f) c = 1.0f;
   }
-  out[0] = c * pre_scale;
-  out[1] = norm;
+  const bool bad = fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  out[0] = bad ? 0.f : c * pre_scale;
+  out[1] = bad ? __uint_as_float(0x7fc00000u) : norm;
+  out[2] = bad ? 1.f : 0.f;
+  out[3] = 0.f;
 }
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(256) void ft_adam_kernel(float* __restrict__ p, con
                                                       float* __restrict__ m, float* __restrict__ v, long n, float lr,
                                                       float b1, float b2, float eps, float bc1, float bc2,
                                                       const float* __restrict__ coef) {
+  if (coef && coef[2] != 0.f) return;             // recurrence fault (ft_clip_coef_kernel): leave p, m, v untouched
   const float c = coef ? coef[0] : 1.0f;
   const float step_size = lr / bc1;
   const float isb2 = 1.0f / sqrtf(bc2);
@@ -102,7 +110,7 @@ int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scal
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ft_sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grads, n, (double*)workspace);
   hipLaunchKernelGGL(ft_clip_coef_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, max_norm, pre_scale,
-                     coef_and_norm);
+                     ft_rnn_fault_word(), coef_and_norm);
   return ft_check_launch("clip_grad_norm");
 }
 

@@ -13,9 +13,13 @@
 //             step * (#producing waves of the shard); workgroup barrier; sc1 16-B loads of the operand rows.
 //   (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", row "each storing wave for itself".)
 // Step s reads parity (s-1)&1 and writes parity s&1; a workgroup can only be one step ahead of the slowest producer it
-// depends on, so two parities suffice.  Every spin is bounded: on timeout the workgroup raises *err and leaves; all
-// others then time out at the same step, so the grid always drains.  All workgroups must be co-resident: the host
-// checks the grid against the occupancy query, otherwise (or with FT_RNN_PERSISTENT=0) the per-step kernels run.
+// depends on, so two parities suffice.  Every spin is bounded: on timeout the workgroup raises the device's STICKY
+// fault word (g_rnn_fault: no launch ever clears it, only ft_rnn_status does) and leaves; all others then time out at
+// the same step, so the grid always drains.  ft_clip_grad_norm / ft_adam_step read that word on the device and skip
+// the update, so a timed-out recurrence can never reach the parameters (trainer.TrainStep surfaces it).  All
+// workgroups must be co-resident: the host admits a launch only while the persistent grids IN FLIGHT on the device
+// (all streams, tracked with events) plus this one fit the occupancy query; otherwise (or with FT_RNN_PERSISTENT=0)
+// the per-step kernels run.
 //
 // What the per-step time is made of (s_memtime phase profile, LSTM 512, B=32: poll 1.0 us, operand loads 0.8,
 // MFMA 0.6, LDS reduce + barrier 0.6, cell 0.6, store drain 0.4, top 0.4) shaped this version:
@@ -27,13 +31,16 @@
 //     lines and the 128-B lines of out / gates / xp rows are shared inside one or two L2s instead of all eight.
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "ft_rnn.h"
 
 namespace {
 
 constexpr int NSH = 16;                // arrival-counter shards per group
 constexpr int CSTRIDE = 32;            // one counter per 128-B line
-constexpr unsigned MAX_SPINS = 1u << 18;
+constexpr unsigned MAX_SPINS_DEFAULT = 1u << 18;
 constexpr int MB = 16;                 // batch rows per workgroup
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -76,7 +83,12 @@ struct Geom {
   int nchunks, nbg, total;             // chunks per group, batch groups, workgroups that have work
   int xcd_aware, sig_per_wave;
   int xcd_off;                         // group-aligned placement: physical XCD of logical slot 0
+  unsigned max_spins;                  // bound of every arrival poll (ft_rnn_set_max_spins; tests force timeouts with it)
 };
+
+// sticky per-device fault word (one 128-B line of its own): set by any workgroup whose poll ran out, cleared only by
+// ft_rnn_status; read on the device by the optimizer kernels (ft_optim.hip) through ft_rnn_fault_word()
+__device__ unsigned g_rnn_fault[32];
 
 __device__ __forceinline__ float4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);     // aux 16 = sc1
@@ -84,15 +96,17 @@ __device__ __forceinline__ float4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned
 }
 
 // wave 0 waits until every shard k holds >= step * n_k arrivals; returns false on timeout (wave-uniform)
-__device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned step, int nprod, int lane) {
+__device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned step, int nprod, int lane,
+                                              unsigned max_spins) {
   bool ok = true;
   if (lane < NSH) {
     const unsigned nk = lane < nprod ? (unsigned)((nprod - lane + NSH - 1) / NSH) : 0u;
     const unsigned target = step * nk;
     unsigned spins = 0;
-    while (__hip_atomic_load(cnt + lane * CSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    if (max_spins == 0) ok = false;        // fault injection (ft_rnn_set_max_spins(-1)): every poll fails at once
+    while (ok && __hip_atomic_load(cnt + lane * CSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > MAX_SPINS) {
+      if (++spins > max_spins) {
         ok = false;
         break;
       }
@@ -119,7 +133,7 @@ __device__ __forceinline__ bool decode(const Geom& g, int& d, int& bgp, int& chu
 // ---------------------------------------------------------------------------------------------------
 template <int G, int NW, bool B3>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
-                                                                     unsigned* err, unsigned xb_bytes) {
+                                                                     unsigned* fault, unsigned xb_bytes) {
   constexpr int UB = 8, NT = 2, BCH = GCH / 2;
   __shared__ float red[NW * NT * 16 * RLD];
   __shared__ int s_ok;
@@ -203,12 +217,12 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     float4 aw[B3 ? BCH : 1][2];
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
+        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
         if (lane == 0) s_ok = ok;
       }
       __syncthreads();
       if (!s_ok) {
-        if (tid == 0) atomicExch(err, 1u);
+        if (tid == 0) atomicExch(fault, 1u);
         return;
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
 // ---------------------------------------------------------------------------------------------------
 template <int G, int NW, int GW, bool B3>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs a, Geom geo, float* xb, unsigned* cnt,
-                                                                     unsigned* err, unsigned xb_bytes) {
+                                                                     unsigned* fault, unsigned xb_bytes) {
   __shared__ float red[NW * 16 * RLD];
   __shared__ int s_ok;
   int d, bgp, chunk, grp;
@@ -418,12 +432,12 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
     float4 aw[B3 ? BW : 1][2];
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
+        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
         if (lane == 0) s_ok = ok;
       }
       __syncthreads();
       if (!s_ok) {
-        if (tid == 0) atomicExch(err, 1u);
+        if (tid == 0) atomicExch(fault, 1u);
         return;
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
 // ---------------------------------------------------------------------------------------------------
 template <int G, int NW, int NT>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Geom geo, float* xb, unsigned* cnt,
-                                                                unsigned* err, unsigned xb_bytes) {
+                                                                unsigned* fault, unsigned xb_bytes) {
   constexpr int ALD = 68;                             // LDS row stride of the local d(gates) tile [16][64]
   constexpr int PC = NW * NT;                         // chunks per group = H / 16 (checked by the host)
   __shared__ __attribute__((aligned(16))) float adg[16 * ALD];
@@ -633,12 +647,12 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
     float rec = 0.f;
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane);
+        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
         if (lane == 0) s_ok = ok;
       }
       __syncthreads();
       if (!s_ok) {
-        if (tid == 0) atomicExch(err, 1u);
+        if (tid == 0) atomicExch(fault, 1u);
         return;
       }
       if (sthr) {       // the P partials of (row ci, unit cj), summed in producer order
@@ -761,31 +775,102 @@ int device_cus() {
 struct PersistWs {
   float* xb;
   unsigned* cnt;
-  unsigned* err;
-  size_t xb_bytes, total_bytes;
+  size_t cnt_bytes, xb_bytes, total_bytes;
 };
-// workspace = [err + counters | exchange buffer]; both zeroed per call
+// workspace = [arrival counters | exchange buffer], zeroed per call from the allocation's start (the fault word is
+// NOT in here: it is the device-global g_rnn_fault, which launches never touch)
 PersistWs carve_ws(void* ws, int ngrp, int K) {
   PersistWs p;
-  size_t cnt_bytes = (size_t)(1 + ngrp * NSH) * CSTRIDE * sizeof(unsigned);
-  p.err = (unsigned*)ws;
-  p.cnt = p.err + CSTRIDE;
+  p.cnt_bytes = (size_t)ngrp * NSH * CSTRIDE * sizeof(unsigned);
+  p.cnt = (unsigned*)ws;
   p.xb_bytes = (size_t)2 * ngrp * (K / 4) * MB * 4 * sizeof(float);
-  p.xb = (float*)((char*)ws + cnt_bytes);
-  p.total_bytes = cnt_bytes + p.xb_bytes;
+  p.xb = (float*)((char*)ws + p.cnt_bytes);
+  p.total_bytes = p.cnt_bytes + p.xb_bytes;
   return p;
 }
 
 // reduce-scatter backward: xb[parity][group][consumer][producer][256]
 PersistWs carve_ws_rs(void* ws, int ngrp, int nchunks) {
   PersistWs p;
-  size_t cnt_bytes = (size_t)(1 + ngrp * NSH) * CSTRIDE * sizeof(unsigned);
-  p.err = (unsigned*)ws;
-  p.cnt = p.err + CSTRIDE;
+  p.cnt_bytes = (size_t)ngrp * NSH * CSTRIDE * sizeof(unsigned);
+  p.cnt = (unsigned*)ws;
   p.xb_bytes = (size_t)2 * ngrp * nchunks * nchunks * 256 * sizeof(float);
-  p.xb = (float*)((char*)ws + cnt_bytes);
-  p.total_bytes = cnt_bytes + p.xb_bytes;
+  p.xb = (float*)((char*)ws + p.cnt_bytes);
+  p.total_bytes = p.cnt_bytes + p.xb_bytes;
   return p;
+}
+
+constexpr int MAX_DEV = 16;
+unsigned g_max_spins = MAX_SPINS_DEFAULT;
+long g_n_persistent = 0, g_n_refused = 0;
+
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = 0;
+  return dev;
+}
+
+// ---- admission: every workgroup of a persistent grid spins until the whole grid is resident, so two such grids on
+// different streams (trunk recurrence on the step's main stream, a predictor's on the side stream) must BOTH fit
+// beside each other, or each could hold the CUs the other is waiting for.  A launch is admitted only while the
+// CU share of the persistent grids still in flight on this device (one event per launch, retired by query) plus its
+// own stays within the chip; a refused launch runs the per-step kernels (always safe).  Non-persistent kernels (GEMMs,
+// RCCL) only delay residency: they finish without waiting for us.
+struct Flight {
+  hipEvent_t ev;
+  double cus;
+};
+std::mutex g_adm_mu;
+std::vector<Flight> g_flights[MAX_DEV];
+std::vector<hipEvent_t> g_ev_pool[MAX_DEV];
+
+template <typename KernelT>
+double grid_cu_share(KernelT kernel, int block, long nblocks) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) return -1.0;
+  if (per_cu > 2) per_cu = 2;      // stay well inside what the dispatcher really admits
+  return (double)nblocks / per_cu;
+}
+
+// true: admitted (call admitted_launch_done after the launch); false: does not fit beside what is in flight
+bool admit(double cus) {
+  if (cus < 0.0 || !ft_rnn_fault_word()) return false;
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(g_adm_mu);
+  auto& fl = g_flights[dev];
+  double busy = 0.0;
+  for (size_t i = 0; i < fl.size();) {
+    if (hipEventQuery(fl[i].ev) == hipSuccess) {
+      g_ev_pool[dev].push_back(fl[i].ev);
+      fl[i] = fl.back();
+      fl.pop_back();
+    } else {
+      busy += fl[i].cus;
+      ++i;
+    }
+  }
+  (void)hipGetLastError();         // hipErrorNotReady of a pending event is not an error
+  const double cap = (double)device_cus() * (env_int("FT_RNN_ADMIT_PCT", 100) / 100.0);
+  if (busy + cus > cap) {
+    ++g_n_refused;
+    return false;
+  }
+  return true;
+}
+
+void admitted_launch_done(double cus, hipStream_t stream) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(g_adm_mu);
+  hipEvent_t ev;
+  if (!g_ev_pool[dev].empty()) {
+    ev = g_ev_pool[dev].back();
+    g_ev_pool[dev].pop_back();
+  } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    return;
+  }
+  (void)hipEventRecord(ev, stream);
+  g_flights[dev].push_back({ev, cus});
+  ++g_n_persistent;
 }
 
 // 1-D grid = 8 x (work items per XCD): the decode hands XCD x the items [x*per, (x+1)*per).  Small layers (<= 64
@@ -811,20 +896,14 @@ int persist_grid(Geom& geo) {
   return 8 * per;
 }
 
-template <typename KernelT>
-bool grid_fits(KernelT kernel, int block, long nblocks) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess) return false;
-  if (per_cu > 2) per_cu = 2;      // stay well inside what the dispatcher really admits
-  return per_cu >= 1 && nblocks <= (long)per_cu * device_cus();
-}
-
 template <int G, int NW, bool B3>
 int launch_fwd_persist(const RnnFwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  if (!grid_fits(ft_rnn_fwd_persist_kernel<G, NW, B3>, NW * 64, grid)) return -1;
-  (void)hipMemsetAsync(p.err, 0, p.total_bytes, stream);
+  const double cus = grid_cu_share(ft_rnn_fwd_persist_kernel<G, NW, B3>, NW * 64, geo.total);
+  if (!admit(cus)) return -1;
+  (void)hipMemsetAsync(p.cnt, 0, p.total_bytes, stream);
   hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
-                     p.err, (unsigned)p.xb_bytes);
+                     ft_rnn_fault_word(), (unsigned)p.xb_bytes);
+  admitted_launch_done(cus, stream);
   return ft_check_launch("rnn_fwd_persistent");
 }
 
@@ -842,6 +921,7 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.total = 2 * geo.nbg * geo.nchunks;
   geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
   geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
+  geo.max_spins = g_max_spins;
   PersistWs p = carve_ws(ws, 2 * geo.nbg, H);
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   const int grid = persist_grid(geo);
@@ -855,20 +935,24 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
 
 template <int G, int NW, int GW, bool B3>
 int launch_bwd_persist(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  if (!grid_fits(ft_rnn_bwd_persist_kernel<G, NW, GW, B3>, NW * 64, grid)) return -1;
-  (void)hipMemsetAsync(p.err, 0, p.total_bytes, stream);
+  const double cus = grid_cu_share(ft_rnn_bwd_persist_kernel<G, NW, GW, B3>, NW * 64, geo.total);
+  if (!admit(cus)) return -1;
+  (void)hipMemsetAsync(p.cnt, 0, p.total_bytes, stream);
   hipLaunchKernelGGL((ft_rnn_bwd_persist_kernel<G, NW, GW, B3>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
-                     p.err, (unsigned)p.xb_bytes);
+                     ft_rnn_fault_word(), (unsigned)p.xb_bytes);
+  admitted_launch_done(cus, stream);
   return ft_check_launch("rnn_bwd_persistent");
 }
 
 template <int G, int NW, int NT>
 int launch_bwd_rs(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  if (!grid_fits(ft_rnn_bwd_rs_kernel<G, NW, NT>, NW * 64, grid)) return -1;
-  // only the status word and the arrival counters need zeroing: every exchange block is written before it is read
-  (void)hipMemsetAsync(p.err, 0, (size_t)((char*)p.xb - (char*)p.err), stream);
-  hipLaunchKernelGGL((ft_rnn_bwd_rs_kernel<G, NW, NT>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt, p.err,
-                     (unsigned)p.xb_bytes);
+  const double cus = grid_cu_share(ft_rnn_bwd_rs_kernel<G, NW, NT>, NW * 64, geo.total);
+  if (!admit(cus)) return -1;
+  // only the arrival counters need zeroing: every exchange block is written before it is read
+  (void)hipMemsetAsync(p.cnt, 0, p.cnt_bytes, stream);
+  hipLaunchKernelGGL((ft_rnn_bwd_rs_kernel<G, NW, NT>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
+                     ft_rnn_fault_word(), (unsigned)p.xb_bytes);
+  admitted_launch_done(cus, stream);
   return ft_check_launch("rnn_bwd_persistent_rs");
 }
 
@@ -910,6 +994,7 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.total = 2 * geo.nbg * geo.nchunks;
   geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
   geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
+  geo.max_spins = g_max_spins;
   const int grid = persist_grid(geo);
   a.s = 0;
   {
@@ -932,6 +1017,18 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
 
 }  // namespace
 
+// device address of this device's sticky fault word (cached per device); nullptr on a HIP error
+unsigned* ft_rnn_fault_word() {
+  static unsigned* cache[MAX_DEV] = {};
+  const int dev = current_device();
+  if (!cache[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_rnn_fault)) != hipSuccess) return nullptr;
+    cache[dev] = (unsigned*)p;
+  }
+  return cache[dev];
+}
+
 int ft_rnn_fwd_persistent(int G, RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {
   return G == 3 ? fwd_persistent<3>(a, ws, ws_bytes, stream) : fwd_persistent<4>(a, ws, ws_bytes, stream);
 }
@@ -944,9 +1041,9 @@ extern "C" {
 size_t ft_rnn_workspace(int gates, int B, int H) {
   if (gates < 3 || gates > 4 || B <= 0 || H <= 0 || H % 16 != 0) return 0;
   const int ngrp = 2 * ft_cdiv(B, MB);
-  PersistWs f = carve_ws(nullptr, ngrp, H);
-  PersistWs b = carve_ws(nullptr, ngrp, gates * H);
-  PersistWs r = carve_ws_rs(nullptr, ngrp, H / 16);
+  const PersistWs f = carve_ws(nullptr, ngrp, H);
+  const PersistWs b = carve_ws(nullptr, ngrp, gates * H);
+  const PersistWs r = carve_ws_rs(nullptr, ngrp, H / 16);
   size_t m = f.total_bytes > b.total_bytes ? f.total_bytes : b.total_bytes;
   return r.total_bytes > m ? r.total_bytes : m;
 }
@@ -957,18 +1054,28 @@ int ft_rnn_set_persistent(int enabled) {
   return old;
 }
 
-int ft_rnn_status(const void* workspace, void* stream) {
-  if (!workspace) return 0;
+int ft_rnn_set_max_spins(int max_spins) {
+  const int old = (int)g_max_spins;
+  g_max_spins = max_spins > 0 ? (unsigned)max_spins : (max_spins < 0 ? 0u : MAX_SPINS_DEFAULT);
+  return old;
+}
+
+int ft_rnn_counters(long* persistent_launches, long* refused_launches) {
+  if (persistent_launches) *persistent_launches = g_n_persistent;
+  if (refused_launches) *refused_launches = g_n_refused;
+  return FT_OK;
+}
+
+int ft_rnn_status(int clear) {
+  unsigned* w = ft_rnn_fault_word();
   unsigned flag = 0;
-  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
-      hipMemcpy(&flag, workspace, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess) {
-    ft_set_error("rnn_status: HIP error while reading the status word");
+  if (!w || hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(&flag, w, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess) {
+    ft_set_error("rnn_status: HIP error while reading the fault word");
     return FT_ERR_HIP;
   }
   if (flag != 0) {
-    // report once: the word is cleared so that a caller who switches to the per-step kernels (which never touch it)
-    // is not told about the same timeout again
-    (void)hipMemset(const_cast<void*>(workspace), 0, sizeof(flag));
+    if (clear) (void)hipMemset(w, 0, sizeof(flag));
     ft_set_error("persistent recurrence timed out waiting for another workgroup (grid not co-resident?); "
                  "set FT_RNN_PERSISTENT=0 to use the per-step kernels");
     return FT_ERR_HIP;

@@ -186,6 +186,13 @@ class ConvBiasFn(Function):
         return dx, dw, db, None
 
 
+def check_posenc_length(T: int, pe: torch.Tensor) -> None:
+    """the kernels index pe[t] for t < T: a sequence longer than the `pe` buffer (max_len = 5000 positions) must fail
+    like the reference's shape error (common_layers.py:144), not read past the buffer"""
+    if T > pe.shape[0] or pe.numel() < T * pe.shape[-1]:
+        raise _lib.FtError(f'PositionalEncoding: sequence of {T} positions exceeds the pe buffer ({pe.shape[0]})')
+
+
 class PosEncFn(Function):
     """x + scale * pe[:T]  (PositionalEncoding.forward, common_layers.py:143-145)."""
 
@@ -193,6 +200,7 @@ class PosEncFn(Function):
     def forward(ctx, x, pe, scale):
         x = _c(x)
         B, T, D = x.shape
+        check_posenc_length(T, pe)
         out = torch.empty_like(x)
         _lib.call('ft_posenc_fwd', x.data_ptr(), pe.data_ptr(), scale.data_ptr(), out.data_ptr(), B, T, D, H._stream())
         ctx.save_for_backward(pe, scale)

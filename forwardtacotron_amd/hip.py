@@ -714,7 +714,6 @@ def masked_l1_bwd(x, target, lens, inv, grad_out: Optional[torch.Tensor], factor
 # ---------------------------------------------------------------------------------------------------
 # All recurrence buffers are TIME-major: xp [T,B,2*G*H], out / cstate [T,B,2H], gates [T,B,2,4H].
 _rnn_ws = {}          # (device, stream, gates, B, H) -> workspace of the persistent recurrence kernels
-_rnn_ws_used = []     # workspaces handed to a kernel since the last check_rnn_status()
 
 
 def _rnn_workspace(gates: int, B: int, H: int, device):
@@ -726,24 +725,23 @@ def _rnn_workspace(gates: int, B: int, H: int, device):
     if ws is None:
         ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         _rnn_ws[key] = ws
-    if not any(w is ws for w in _rnn_ws_used):
-        _rnn_ws_used.append(ws)
     return ws, nbytes
 
 
-def check_rnn_status() -> None:
-    """Synchronises and raises if any persistent recurrence launched since the last check timed out
-    (tests, smoke and bench call this; a training loop can call it every N steps)."""
-    used = list(_rnn_ws_used)
-    _rnn_ws_used.clear()
-    first = None
-    for ws in used:                 # visit every workspace (each visit also clears a raised status word)
-        try:
-            _lib.call('ft_rnn_status', _p(ws), _stream())
-        except _lib.FtError as e:
-            first = first or e
-    if first is not None:
-        raise first
+def check_rnn_status(clear: bool = True) -> None:
+    """Synchronises the device and raises if ANY persistent recurrence launched on it since the fault word was last
+    cleared timed out (the word is sticky: later launches, successful or not, never reset it).  clear=True resets it, so
+    that a caller who switches to the per-step kernels is not told about the same timeout again.  Training does not
+    depend on anyone calling this: the optimizer kernels read the same word on the device and skip the update
+    (trainer.TrainStep)."""
+    _lib.call('ft_rnn_status', int(clear))
+
+
+def rnn_counters():
+    """(launches that ran in the persistent form, launches refused admission -> per-step kernels) since load"""
+    a, b = ctypes.c_long(0), ctypes.c_long(0)
+    _lib.call('ft_rnn_counters', ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
 
 
 def gru_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool):

@@ -92,10 +92,11 @@ class LSTM(_RNNParams):
 class LengthRegulator(nn.Module):
     """common_layers.py:12-24"""
 
-    def forward(self, x: torch.Tensor, dur: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, dur: torch.Tensor, pack_lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """pack_lens: lengths the result will be packed with (see ops.LengthRegulateFn); None = reference signature"""
         if not dur.is_contiguous() or dur.dtype != torch.float32:
             raise H._lib.FtError('LengthRegulator: dur must be contiguous fp32 (it is clamped in place)')
-        return ops.LengthRegulateFn.apply(x, dur)
+        return ops.LengthRegulateFn.apply(x, dur, pack_lens)
 
 
 class HighwayNetwork(nn.Module):
@@ -247,6 +248,7 @@ class ForwardTacotron(nn.Module):
                  prenet_dropout: float, postnet_dims: int, postnet_k: int, prenet_num_highways: int,
                  postnet_dropout: float, n_mels: int, padding_value=PAD_VALUE):
         super().__init__()
+        self._ctor_kwargs = {k: v for k, v in locals().items() if k not in ('self', '__class__')}
         self.rnn_dims = rnn_dims
         self.padding_value = padding_value
         self.embedding = nn.Embedding(num_chars, embed_dims)
@@ -309,7 +311,7 @@ class ForwardTacotron(nn.Module):
         x = ops.CondAddFn.apply(x, pitch, energy, self.pitch_proj.weight, self.pitch_proj.bias,
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
                                 self.energy_strength, True)                 # -> [B,Tx,2P]
-        x = self.lr(x, dur)
+        x = self.lr(x, dur, mel_lens)       # at max(mel_lens) frames, the length pad_packed_sequence returns (:147-152)
         x = self.lstm(x, mel_lens, self.padding_value)
         mel = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)        # [B,T,n_mels]
         post = self.postnet(mel, time_major_out=True)                       # [T,B,2Q]
@@ -370,9 +372,16 @@ class ForwardTacotron(nn.Module):
             return self._generate(x, alpha, pitch_function, energy_function)
 
     def generate_jit(self, x: torch.Tensor, alpha: float = 1.0, beta: float = 1.0) -> Dict[str, torch.Tensor]:
-        """Same contract as forward_tacotron.py:186-200 (pitch scaled by beta); plain method, not TorchScript."""
+        """forward_tacotron.py:186-200: generate with the pitch scaled by beta.  Eager entry; the TorchScript surface
+        (`torch.jit.script(model).generate_jit`, README.md:159-171 of the reference) is export.ScriptedForwardTacotron,
+        which reaches this same path through the opaque operator torch.ops.fwdtaco.generate_jit."""
         with torch.no_grad():
             return self._generate(x, alpha, lambda p: ops.ScaleFn.apply(p, beta) if beta != 1.0 else p, lambda e: e)
+
+    def __prepare_scriptable__(self):
+        """torch.jit.script(model) compiles the flat-buffer twin (export.py), not this kernel-launching module tree."""
+        from . import export
+        return export.scriptable(self, self._ctor_kwargs)
 
     def _generate(self, x, alpha, pitch_function, energy_function):
         self._require_device(x)
@@ -409,3 +418,6 @@ class ForwardTacotron(nn.Module):
         model = ForwardTacotron.from_config(checkpoint['config'])
         model.load_state_dict(checkpoint['model'])
         return model
+
+
+from . import export as _export  # noqa: E402,F401  (registers torch.ops.fwdtaco.generate_jit for torch.jit.load)

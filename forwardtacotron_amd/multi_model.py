@@ -154,7 +154,7 @@ class MultiForwardTacotron(nn.Module):
         x = ops.CondAddFn.apply(x, pitch, energy, self.pitch_proj.weight, self.pitch_proj.bias,
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
                                 self.energy_strength, False)
-        x = self.lr(x, dur)
+        x = self.lr(x, dur, mel_lens)       # at max(mel_lens) frames, the length pad_packed_sequence returns
         x = self.lstm(x, mel_lens, self.padding_value)
         mel = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)
         post = self.postnet(mel, time_major_out=True)

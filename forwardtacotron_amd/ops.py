@@ -550,13 +550,28 @@ class CondAddFn(Function):
 
 class LengthRegulateFn(Function):
     """LengthRegulator.forward (common_layers.py:17-24).  Clamps `dur` in place like the reference.
-    One host sync reads max_b sum_j r_bj to size the output (the reference syncs here too)."""
+    One host sync reads max_b sum_j r_bj to size the output (the reference syncs here too).
+
+    pack_lens (optional int64 [B], device): the lengths the CALLER is about to pack the result with
+    (forward_tacotron.py:147-152).  pad_packed_sequence returns max(pack_lens) frames, so everything downstream of the
+    LSTM (lin, postnet BatchNorm statistics, GRU) sees exactly that many; the expansion is therefore produced at
+    min(T_lr, max(pack_lens)) frames right away (frames beyond it are never read by a packed LSTM and get no
+    gradient).  max(pack_lens) > T_lr makes the reference's LSTM raise; so does this (same sync, no extra one)."""
 
     @staticmethod
-    def forward(ctx, x, dur):
+    def forward(ctx, x, dur, pack_lens=None):
         x = _c(x)
         cum, total = H.lr_scan(dur)
-        Tm = int(total.max().item()) if total.numel() else 0
+        if total.numel() == 0:
+            Tm = 0
+        elif pack_lens is None:
+            Tm = int(total.max().item())
+        else:
+            Tm, Lmax = torch.stack([total.max().long(), pack_lens.max().long()]).tolist()
+            if Lmax > Tm:
+                raise H._lib.FtError(f'LengthRegulator: an item is to be packed with {Lmax} frames but the rounded '
+                                     f'durations expand to at most {Tm} (the reference fails in its packed LSTM here)')
+            Tm = Lmax
         ctx.save_for_backward(cum)
         ctx.Tx = x.shape[1]
         return H.lr_expand(x, cum, Tm)
@@ -564,7 +579,7 @@ class LengthRegulateFn(Function):
     @staticmethod
     def backward(ctx, dy):
         (cum,) = ctx.saved_tensors
-        return H.lr_bwd(_c(dy), cum, ctx.Tx), None
+        return H.lr_bwd(_c(dy), cum, ctx.Tx), None, None
 
 
 class TransposePadFn(Function):

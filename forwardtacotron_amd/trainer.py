@@ -8,6 +8,14 @@ kernels over the flat parameter / gradient buffers (no per-tensor loop, no host 
 group the flat gradient is sum-all-reduced in buckets overlapped with backward (RCCL over xGMI) and the
 1/world factor is folded into the clip coefficient.  BatchNorm statistics stay per rank (the reference has
 no SyncBN), every rank applies the identical Adam update.
+
+Recurrence faults.  The persistent recurrences poll other workgroups with bounded spins; a poll that runs out leaves
+garbage in that step's activations / gradients and sets the device's sticky fault word.  The clip kernel reads the word
+ON THE DEVICE: the Adam kernel then leaves parameters and moments untouched, the reported grad_norm is NaN, and
+`out['rnn_fault']` is 1.  The host learns about it without a per-step sync: the flag of every step is copied to pinned
+memory asynchronously and looked at when a later step (or `check()`) finds the copy complete.  Policy `on_rnn_fault`:
+'raise' (default) raises FtError; 'fallback' clears the word, switches the library to the per-step recurrence kernels
+and carries on (the faulted steps made no update; their BatchNorm running statistics and `step` increments remain).
 """
 import os
 from typing import Dict, Optional
@@ -26,7 +34,8 @@ DEFAULT_TRAIN_CFG = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss
 
 class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float, train_cfg: Optional[dict] = None,
-                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_bytes: int = 24 << 20):
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_bytes: int = 24 << 20,
+                 on_rnn_fault: str = 'raise'):
         self.model = model
         self.lr = float(lr)
         self.cfg = dict(DEFAULT_TRAIN_CFG)
@@ -40,7 +49,14 @@ class TrainStep:
         self.exp_avg = torch.zeros_like(self.flat.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat)
         self.opt_step = 0
-        self.coef = torch.zeros(2, device=dev, dtype=torch.float32)      # [clip coefficient, grad norm]
+        # ft_clip_grad_norm's record: [clip coefficient, grad norm, recurrence-fault flag, 0]
+        self.coef = torch.zeros(4, device=dev, dtype=torch.float32)
+        if on_rnn_fault not in ('raise', 'fallback'):
+            raise ValueError("on_rnn_fault must be 'raise' or 'fallback'")
+        self.on_rnn_fault = on_rnn_fault
+        self._fault_slots = []          # ring of (pinned host float[1], event, optimizer step it belongs to or None)
+        self._fault_next = 0
+        self.skipped_steps = 0          # optimizer steps the device skipped because of a recurrence fault
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = BucketedAllReduce(self.flat, process_group, bucket_bytes)
         # weight gradients are written straight into the flat buffer, the GEMM-shaped ones on a side stream
@@ -97,6 +113,7 @@ class TrainStep:
         """batch: device tensors with the ForwardCollator layout (utils/dataset.py:239-263).  Returns the
         loss terms and the pre-clip gradient norm as device scalars (no host sync in here except the
         LengthRegulator's output-size read, which the reference has too)."""
+        self._poll_faults(wait=False)       # a fault of an EARLIER step whose flag has reached the host by now
         if self.main_stream is None:
             return self._step(batch)
         # the step's critical path runs on a HIGH-priority stream: its bandwidth-bound kernels (BatchNorm statistics,
@@ -154,8 +171,64 @@ class TrainStep:
         self.reducer.finish()
         self.optimizer_step()
         out = {k: v.detach() for k, v in L.items()}
-        out['grad_norm'] = self.coef[1]
+        out['grad_norm'] = self.coef[1]         # NaN if a recurrence faulted (the update was skipped on the device)
+        out['rnn_fault'] = self.coef[2]
+        self._post_fault_flag()
         return out
+
+    # -- recurrence-fault surfacing (no per-step host sync) ------------------------------------------------
+    def _post_fault_flag(self) -> None:
+        """async copy of this step's fault flag into a pinned slot; looked at by a later step / check()"""
+        if len(self._fault_slots) < 8:
+            self._fault_slots.append([torch.zeros(1, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None])
+        slot = self._fault_slots[self._fault_next % len(self._fault_slots)]
+        self._fault_next += 1
+        if slot[2] is not None:             # ring wrapped onto a copy nobody has looked at yet: look now
+            slot[1].synchronize()
+            self._consume(slot)
+        slot[0].copy_(self.coef[2:3], non_blocking=True)
+        slot[1].record()
+        slot[2] = self.opt_step
+
+    def _consume(self, slot) -> None:
+        step_no, bad = slot[2], float(slot[0][0]) != 0.0
+        slot[2] = None
+        if bad:
+            self._handle_fault(step_no)
+
+    def _poll_faults(self, wait: bool) -> None:
+        for slot in sorted((s for s in self._fault_slots if s[2] is not None), key=lambda s: s[2]):
+            if slot[2] is None:             # an earlier slot's fault handling already dealt with everything pending
+                continue
+            if wait:
+                slot[1].synchronize()
+            elif not slot[1].query():
+                continue
+            self._consume(slot)
+
+    def _handle_fault(self, first_bad_step: int) -> None:
+        # the fault word is sticky: every optimizer step from `first_bad_step` on was skipped on the device
+        torch.cuda.synchronize()
+        self.skipped_steps += self.opt_step - (first_bad_step - 1)
+        self.opt_step = first_bad_step - 1          # Adam's bias correction continues where the last real update was
+        for slot in self._fault_slots:
+            slot[2] = None
+        try:
+            H.check_rnn_status(clear=True)
+        except _lib.FtError:
+            pass
+        msg = (f'persistent recurrence timed out in optimizer step {first_bad_step}: that update (and every later one) '
+               f'was skipped on the device, parameters are intact')
+        if self.on_rnn_fault == 'fallback':
+            _lib.query('ft_rnn_set_persistent', 0)
+            import warnings
+            warnings.warn(msg + '; continuing with the per-step recurrence kernels')
+            return
+        raise _lib.FtError(msg + "; construct TrainStep(on_rnn_fault='fallback') to continue on the per-step kernels")
+
+    def check(self) -> None:
+        """Waits for every step issued so far and raises (or falls back) if one of them hit a recurrence fault."""
+        self._poll_faults(wait=True)
 
     def optimizer_step(self) -> None:
         f = self.flat

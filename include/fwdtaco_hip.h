@@ -19,7 +19,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define FWDTACO_ABI_VERSION 1
+#define FWDTACO_ABI_VERSION 2
 
 #ifdef __cplusplus
 extern "C" {
@@ -270,12 +270,20 @@ int ft_masked_l1_bwd(const float* x, const float* target, const long* lens, cons
 /* `workspace` (ft_rnn_workspace(gates,B,H) bytes, may be NULL) enables the PERSISTENT form: one launch runs all T
  * steps with W_hh resident in registers and h exchanged between workgroups inside the kernel (bounded spins).
  * It is used when H % 16 == 0, the grid is co-resident per the occupancy query and FT_RNN_PERSISTENT != 0;
- * otherwise one kernel per timestep is launched.  The first 4 bytes of the workspace are a status word
- * (non-zero = a workgroup timed out); ft_rnn_status() synchronises the stream and reads it. */
+ * otherwise one kernel per timestep is launched.  A launch is admitted only while the persistent grids still in flight
+ * on the device (any stream) plus its own fit the chip, because every workgroup spins until its whole grid is resident.
+ * Faults: a workgroup whose bounded poll runs out sets the device's STICKY fault word and leaves (the grid drains);
+ * no launch clears that word.  ft_clip_grad_norm / ft_adam_step read it on the device and skip the parameter update;
+ * ft_rnn_status(clear) synchronises the device, returns an error if the word is set and (clear != 0) resets it. */
 size_t ft_rnn_workspace(int gates, int B, int H);
-int ft_rnn_status(const void* workspace, void* stream);
+int ft_rnn_status(int clear);
 /* runtime override of FT_RNN_PERSISTENT (1 = allow the persistent form); returns the previous setting */
 int ft_rnn_set_persistent(int enabled);
+/* bound of the arrival polls (0 restores the default 2^18; -1 = fault injection for tests: every poll of every
+ * later launch fails at once, deterministically); returns the previous bound (0 while injecting) */
+int ft_rnn_set_max_spins(int max_spins);
+/* launches that ran in the persistent form / that were refused admission (and ran per-step) since the library loaded */
+int ft_rnn_counters(long* persistent_launches, long* refused_launches);
 int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
                float* out, float* gates, int B, int T, int H, void* workspace, size_t workspace_bytes,
                void* stream);
@@ -302,13 +310,16 @@ int ft_mask_rows(const float* src, const long* lens, float* dst, int B, int T, i
 int ft_bt_transpose(const float* src, float* dst, int B, int T, int C, int dst_time_major, void* stream);
 
 /* ---- clip_grad_norm_ + torch.optim.Adam (trainer/forward_trainer.py:95-99 ; train_forward.py:76) ------ */
-/* over FLAT fp32 buffers (all parameters back to back, 16-B aligned).  coef_and_norm[0] = pre_scale *
- * min(1, max_norm/(norm+1e-6)), [1] = norm = pre_scale*||grads||_2 (pre_scale = 1/world_size when the buffer
- * holds an all-reduced SUM); max_norm <= 0 disables clipping.  Stays on device: no host sync. */
+/* over FLAT fp32 buffers (all parameters back to back, 16-B aligned).  coef_and_norm holds FOUR floats:
+ * [0] = pre_scale * min(1, max_norm/(norm+1e-6)), [1] = norm = pre_scale*||grads||_2 (pre_scale = 1/world_size when
+ * the buffer holds an all-reduced SUM), [2] = 1 if the device's recurrence-fault word is set (then [0] = 0, [1] = NaN and
+ * ft_adam_step leaves params / moments untouched), [3] = 0; max_norm <= 0 disables clipping.  Stays on device: no host
+ * sync. */
 size_t ft_grad_norm_workspace(void);
 int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scale, float* coef_and_norm,
                       void* workspace, size_t workspace_bytes, void* stream);
-/* Adam, torch defaults semantics (no weight decay / amsgrad): g = grads*coef[0]; step counts from 1 */
+/* Adam, torch defaults semantics (no weight decay / amsgrad): g = grads*coef[0]; step counts from 1; coef (may be NULL)
+ * is ft_clip_grad_norm's 4-float record: a set [2] skips the update */
 int ft_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                  float beta2, float eps, long step, const float* coef, void* stream);
 

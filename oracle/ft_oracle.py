@@ -192,6 +192,14 @@ def lstm_direction(x: Tensor, lens: Optional[Tensor], w_ih: Tensor, w_hh: Tensor
 
 def bilstm(x: Tensor, lens: Optional[Tensor], P: Dict[str, Tensor], prefix: str,
            pad_value: float = PAD_VALUE) -> Tensor:
+    """With ``lens``: pad_packed_sequence returns max(lens) frames (forward_tacotron.py:151), so an input expanded to
+    more frames than that is cut there (the packed LSTM never reads the rest); an item longer than the input makes the
+    reference's packed LSTM raise -- so does this."""
+    if lens is not None:
+        Lmax = int(lens.max())
+        if Lmax > x.shape[1]:
+            raise RuntimeError(f'packed length {Lmax} exceeds the {x.shape[1]} frames of the input')
+        x = x[:, :Lmax]
     f = lstm_direction(x, lens, P[prefix + 'weight_ih_l0'], P[prefix + 'weight_hh_l0'],
                        P[prefix + 'bias_ih_l0'], P[prefix + 'bias_hh_l0'], False, pad_value)
     r = lstm_direction(x, lens, P[prefix + 'weight_ih_l0_reverse'],

@@ -360,6 +360,73 @@ def test_full_size_properties(ft):
     assert 0 < worst <= 1e-4 * 1.01          # lr, plus the fp32 rounding of p - delta for |p| up to ~1
 
 
+def test_expanded_length_beyond_mel_len_golden(ft):
+    """tests/golden/tiny_crop.npz (captured from the reference): rounded durations expand to T_lr = max(mel_len) + 5;
+    pad_packed_sequence returns max(mel_len) frames, so lin / the postnet's BatchNorm statistics / GRU run on that many.
+    And the error case: an item packed with more frames than its durations give raises like the reference's LSTM."""
+    model, ops, hip = ft
+    M, C = load_npz('tiny_model.npz'), load_npz('tiny_crop.npz')
+    m = load_sd(model.ForwardTacotron(**TINY), sub(M, 'sd/')).cuda()
+    batch = sub(C, 'batch/')
+    pred, L, _ = _train_step_hip(model, ops, m, batch, TRAIN_CFG)
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+        assert pred[k].shape == C['train/' + k].shape, k
+        assert maxdiff(pred[k].detach().cpu(), C['train/' + k]) < 5e-5, k
+    assert abs(float(L['loss']) - float(C['loss/total'])) < 2e-5
+    worst = max(maxdiff(p.grad.cpu(), C['grad/' + k]) for k, p in m.named_parameters())
+    assert worst < 1e-4, worst
+    sd = m.state_dict()
+    for k, v in sub(C, 'sd_after/').items():
+        assert maxdiff(sd[k].cpu(), v) < 1e-5, k
+    bad = sub(M, 'batch/')
+    bad['mel_len'] = bad['mel_len'].clone()
+    bad['mel_len'][int(bad['mel_len'].argmax())] += 2
+    with pytest.raises(hip._lib.FtError, match='packed'):
+        m(cuda_batch(bad))
+
+
+def test_generate_jit_beta_scales_the_pitch(ft):
+    """forward_tacotron.py:186-200: generate_jit(x, alpha, beta) == generate(x, alpha, pitch_function = p * beta);
+    checked against generate() of this module AND against the oracle's generate with the same pitch function."""
+    model, ops, hip = ft
+    from oracle import ft_oracle as O
+    G = load_npz('generate.npz')
+    sd = sub(G, 'sd/')
+    m = load_sd(model.ForwardTacotron(**TINY), sd).cuda().eval()
+    x = torch.from_numpy(G['b2/x'])
+    for alpha, beta in ((1.0, 1.0), (0.9, 1.7), (1.3, 0.4)):
+        got = m.generate_jit(x.cuda(), alpha, beta)
+        ref = m.generate(x.cuda(), alpha=alpha, pitch_function=lambda p: p * beta)
+        want = O.generate(sd, x, TINY, alpha=alpha, pitch_function=lambda p: p * beta)
+        for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+            assert got[k].shape == want[k].shape, (k, alpha, beta)
+            assert maxdiff(got[k].cpu(), ref[k].cpu()) < 1e-6, (k, alpha, beta)
+            assert maxdiff(got[k].cpu(), want[k]) < 5e-5, (k, alpha, beta)
+    base = m.generate_jit(x.cuda(), 1.0, 1.0)
+    assert maxdiff(m.generate_jit(x.cuda(), 1.0, 2.0)['pitch'].cpu(), 2.0 * base['pitch'].cpu()) < 1e-6
+
+
+def test_torchscript_generate_jit(ft, tmp_path):
+    """README.md:159-171 of the reference on the drop-in: torch.jit.script(model).generate_jit on the GPU, before and
+    after torch.jit.save / load, equals the eager generate_jit and the reference's generate() golden (beta = 1)."""
+    model, ops, hip = ft
+    G = load_npz('generate.npz')
+    m = load_sd(model.ForwardTacotron(**TINY), sub(G, 'sd/')).cuda().eval()
+    s = torch.jit.script(m)
+    path = str(tmp_path / 'ft_script.pt')
+    s.save(path)
+    loaded = torch.jit.load(path, map_location='cuda')
+    x = torch.from_numpy(G['b2/x']).cuda()
+    for mod in (s, loaded):
+        out = mod.generate_jit(x, 0.9, 1.0)
+        for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+            assert maxdiff(out[k].cpu(), G[f'b2/{k}']) < 5e-5, k
+        a, b = mod.generate_jit(x, 1.2, 0.5), m.generate_jit(x, 1.2, 0.5)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+        assert set(mod(x).keys()) == {'mel', 'mel_post', 'dur', 'pitch', 'energy'}
+
+
 def test_cpu_tensors_are_refused(ft):
     model, ops, hip = ft
     m = model.ForwardTacotron(**TINY)

@@ -3,7 +3,7 @@ and vs two consecutive oracle steps."""
 import pytest
 import torch
 
-from helpers import TINY, TRAIN_CFG, load_npz, sub, maxdiff
+from helpers import TINY, TRAIN_CFG, load_npz, sub, maxdiff  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -148,3 +148,113 @@ def test_deferred_weight_gradients_wait_for_the_emitting_stream():
         assert float(view.min()) == 3.0 and float(view.max()) == 3.0
     finally:
         ops.set_grad_sink(None)
+
+
+# ---------------------------------------------------------------------------------------------------
+# recurrence faults: a persistent recurrence whose poll runs out must never reach the parameters
+# ---------------------------------------------------------------------------------------------------
+def _force_timeouts(on: bool):
+    from forwardtacotron_amd import _lib
+    return _lib.lib().ft_rnn_set_max_spins(-1 if on else 0)
+
+
+def test_recurrence_fault_is_sticky_across_later_launches():
+    """a timed-out launch's status must survive later successful launches on the same workspace."""
+    from forwardtacotron_amd import _lib, hip as H
+    torch.manual_seed(0)
+    B, T, Hh = 4, 40, 64
+    xp = torch.randn(T, B, 6 * Hh, device='cuda')
+    w = [torch.randn(3 * Hh, Hh, device='cuda') * 0.1 for _ in range(2)]
+    b = [torch.randn(3 * Hh, device='cuda') * 0.1 for _ in range(2)]
+    H.check_rnn_status()
+    good, _ = H.gru_fwd(xp, w[0], w[1], b[0], b[1], Hh, save_gates=False)
+    H.check_rnn_status()
+    n0 = H.rnn_counters()[0]
+    _force_timeouts(True)                     # fault injection: every arrival poll fails at once
+    try:
+        H.gru_fwd(xp, w[0], w[1], b[0], b[1], Hh, save_gates=False)
+    finally:
+        _force_timeouts(False)
+    again, _ = H.gru_fwd(xp, w[0], w[1], b[0], b[1], Hh, save_gates=False)     # same workspace, succeeds
+    assert H.rnn_counters()[0] == n0 + 2, 'the persistent form must have run (else this test tests nothing)'
+    with pytest.raises(_lib.FtError):
+        H.check_rnn_status(clear=False)       # ... and the earlier fault is still reported
+    with pytest.raises(_lib.FtError):
+        H.check_rnn_status()                  # reported again, now cleared
+    H.check_rnn_status()
+    assert torch.equal(good, again)
+
+
+def _smoke_model():
+    from forwardtacotron_amd.model import ForwardTacotron
+    cfg = dict(TINY, rnn_dims=32, postnet_dims=32, durpred_rnn_dims=16)    # persistent-eligible recurrences (H % 16 == 0)
+    torch.manual_seed(3)
+    return ForwardTacotron(**cfg).cuda(), cfg
+
+
+def test_recurrence_fault_skips_the_update_and_raises():
+    """forced timeout -> parameters and Adam moments unchanged, grad_norm NaN, FtError surfaced by the
+    NEXT step without anybody calling check_rnn_status; after that the trainer works again and matches a clean twin."""
+    from forwardtacotron_amd import _lib, hip as H
+    from forwardtacotron_amd.trainer import TrainStep
+    from oracle import ft_oracle as O
+    m, cfg = _smoke_model()
+    twin, _ = _smoke_model()
+    twin.load_state_dict(m.state_dict())
+    batch = O.synthetic_batch(B=4, Tmax=12, n_mels=10, max_dur=5, seed=1)
+    dev = lambda: {k: v.clone().cuda() for k, v in batch.items()}
+    ts = TrainStep(m, lr=1e-3, train_cfg=TRAIN_CFG)
+    ts2 = TrainStep(twin, lr=1e-3, train_cfg=TRAIN_CFG)
+    H.check_rnn_status()
+    ts.step(dev()); ts2.step(dev())
+    ts.check()
+    before = ts.flat.flat.clone()
+    m1, v1 = ts.exp_avg.clone(), ts.exp_avg_sq.clone()
+    n0 = H.rnn_counters()[0]
+    _force_timeouts(True)
+    try:
+        out = ts.step(dev())
+        torch.cuda.synchronize()
+    finally:
+        _force_timeouts(False)
+    assert H.rnn_counters()[0] > n0
+    assert float(out['rnn_fault']) == 1.0 and torch.isnan(out['grad_norm'])
+    assert torch.equal(ts.flat.flat, before) and torch.equal(ts.exp_avg, m1) and torch.equal(ts.exp_avg_sq, v1)
+    with pytest.raises(_lib.FtError, match='timed out'):
+        ts.step(dev())                        # the previous step's flag has reached the host: raised BEFORE this step runs
+    assert ts.opt_step == 1 and ts.skipped_steps == 1
+    H.check_rnn_status()                      # the handler cleared the word
+    out = ts.step(dev()); out2 = ts2.step(dev())
+    ts.check(); ts2.check()
+    assert float(out['rnn_fault']) == 0.0
+    # BatchNorm running stats saw one extra (skipped) forward in `m`; trainable parameters must agree with the twin
+    assert maxdiff(ts.flat.flat.cpu(), ts2.flat.flat.cpu()) < 1e-6
+    assert abs(float(out['grad_norm']) - float(out2['grad_norm'])) < 1e-5
+
+
+def test_recurrence_fault_fallback_policy_continues_on_per_step_kernels():
+    from forwardtacotron_amd import _lib, hip as H
+    from forwardtacotron_amd.trainer import TrainStep
+    from oracle import ft_oracle as O
+    m, cfg = _smoke_model()
+    batch = O.synthetic_batch(B=4, Tmax=12, n_mels=10, max_dur=5, seed=1)
+    dev = lambda: {k: v.clone().cuda() for k, v in batch.items()}
+    ts = TrainStep(m, lr=1e-3, train_cfg=TRAIN_CFG, on_rnn_fault='fallback')
+    H.check_rnn_status()
+    _force_timeouts(True)
+    try:
+        ts.step(dev())
+        torch.cuda.synchronize()
+    finally:
+        _force_timeouts(False)
+    try:
+        with pytest.warns(UserWarning, match='per-step'):
+            ts.check()
+        n0 = H.rnn_counters()[0]
+        out = ts.step(dev())
+        ts.check()
+        assert H.rnn_counters()[0] == n0, 'per-step kernels expected after the fallback'
+        assert float(out['rnn_fault']) == 0.0 and bool(torch.isfinite(out['grad_norm']))
+        assert ts.opt_step == 1 and ts.skipped_steps == 1
+    finally:
+        _lib.lib().ft_rnn_set_persistent(1)

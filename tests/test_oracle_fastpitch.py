@@ -55,3 +55,16 @@ def test_generate(Z, tag, alpha):
     assert out['mel'].shape == Z[tag + '/mel'].shape
     for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
         assert maxdiff(out[k], Z[f'{tag}/{k}']) < 1e-5, k
+
+
+def test_positional_encoding_refuses_sequences_beyond_the_pe_buffer():
+    """FastPitch.generate with more than max_len = 5000 frames must raise (the reference fails with a shape
+    error at common_layers.py:144), not index past the buffer.  Host-side check: runs without a GPU."""
+    import pytest
+    import torch
+    from forwardtacotron_amd import _lib
+    from forwardtacotron_amd.fastpitch import check_posenc_length
+    pe = torch.zeros(5000, 1, 8)
+    check_posenc_length(5000, pe)
+    with pytest.raises(_lib.FtError, match='exceeds the pe buffer'):
+        check_posenc_length(5001, pe)

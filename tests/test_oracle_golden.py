@@ -159,3 +159,25 @@ def test_tiny_multispeaker_model():
     for k, v in sub(M, 'sd_after/').items():
         if v.dtype.is_floating_point:
             assert maxdiff(newP[k], v) < 2e-5, k
+
+
+def test_expanded_length_beyond_mel_len_is_cut_at_the_packed_length():
+    """tests/golden/make_golden_crop.py: T_lr = max(mel_len) + 5.  pad_packed_sequence returns max(mel_len) frames, so
+    lin / postnet BatchNorm statistics / GRU see that many (forward_tacotron.py:147-152)."""
+    M, C = load_npz('tiny_model.npz'), load_npz('tiny_crop.npz')
+    P = sub(M, 'sd/')
+    batch = sub(C, 'batch/')
+    assert int(C['t_lr']) > int(batch['mel_len'].max())
+    newP, _, info = O.train_step(P, {}, batch, TINY, TRAIN_CFG, lr=1e-3, step_count=1)
+    for k in ('mel', 'mel_post', 'dur', 'pitch', 'energy'):
+        assert maxdiff(info['pred'][k], C['train/' + k]) < 2e-5, k
+    assert abs(float(info['losses']['loss']) - float(C['loss/total'])) < 1e-5
+    assert max(maxdiff(g, C['grad/' + k]) for k, g in info['grads'].items()) < 1e-4
+    for k, v in sub(C, 'sd_after/').items():
+        assert maxdiff(info['new_buffers'][k] if 'new_buffers' in info else newP[k], v) < 1e-5, k
+    # an item packed with more frames than its durations expand to: the reference's LSTM raises
+    bad = sub(M, 'batch/')
+    bad['mel_len'] = bad['mel_len'].clone()
+    bad['mel_len'][int(bad['mel_len'].argmax())] += 2
+    with pytest.raises(RuntimeError):
+        O.forward(P, bad, TINY, training=True)
