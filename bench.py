@@ -10,12 +10,17 @@ Tm=841, 19,320 valid frames on rank 0's seed), singlespeaker.yaml model, fp32, d
 inputs resident in HBM before the timed region.  Weak scaling: every rank draws its own bs=32 batch.
 
 Rank 0 prints ONE JSON line (driver contract) with two extra objects:
-  roofline     : MFMA roofline of the dominant GEMM launch (postnet conv bank forward), timed live with HIP events
-                 on its launch stream inside every timed step: algorithmic fp32 TFLOP/s against the f32 MFMA peak,
-                 and -- the kernel runs fp32 products as exact 3-way bf16 splits on the bf16 matrix pipe -- the
-                 executed bf16 rate against the dense bf16 peak; plus whole-step achieved TFLOP/s in `step`
-  cpu_baseline : the CPU oracle (port of the reference step) timed on this box's host cores on a bounded
-                 sample of the same workload (rank 0, N=1 only)
+  roofline     : the dominant GEMM launch (postnet conv bank forward) timed LIVE with a HIP event pair on its launch
+                 stream inside every timed step -- algorithmic fp32 TFLOP/s against the f32 MFMA peak, the executed bf16
+                 rate against the dense bf16 peak, HBM traffic per launch read from the committed PMC summary named in
+                 `traffic_source` -- plus `families`: the TIME-dominant kernel family (the persistent recurrences,
+                 latency-bound) and the LengthRegulator (HBM-bound), timed with event pairs in a short instrumented pass
+                 AFTER the timed region (32 extra event records per step would perturb it), and whole-step TFLOP/s
+  cpu_baseline : the reference step restated on stock fused torch CPU ops (oracle/ft_torch_cpu.py, pinned to the
+                 reference goldens by tests/test_cpu_baseline.py) on the SAME bs=32 seed-0 batch, on this box's host cores
+                 (rank 0, N=1 only), as many whole steps as fit the --cpu-budget after a small warm-up
+The event pairs are owned by this file: it wraps the package's launch wrappers (forwardtacotron_amd.hip.*) for the
+duration of a measurement; the product carries no timing hook.
 """
 import argparse
 import json
@@ -31,28 +36,76 @@ if ROOT not in sys.path:
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide; AMD's 5 PF headline includes 2:1 sparsity)
-
+HBM_PEAK_TBS = 8.0                # HBM3E spec (6.3 TB/s achievable per the guide)
 
 BANK_SHAPE = (32, 841, 80, 256, 8)      # B, T, Cin, C, K of the postnet conv bank forward at the benchmark config
+TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_bank_fwd.json')    # written by tools/pmc_traffic.py from --pmc passes
 
 
-def dominant_kernel_roofline(events):
-    """The dominant GEMM-shaped launch of the step -- the postnet conv bank forward, one ft_gemm_rows_kernel<2,2,NT>
-    launch (M = 32*842 rows, 8 members k=1..8, Cin 80 -> 256: 2*B*(T+1)*80*256*36 FLOP) -- timed LIVE: HIP events
-    recorded around that launch on its own stream inside every timed step (forwardtacotron_amd.hip.bank_probe)."""
+class Probes:
+    """HIP event pairs around selected launch wrappers of forwardtacotron_amd.hip, recorded on the stream the wrapper
+    launches on (torch's current stream at call time)."""
+
+    def __init__(self, hip_mod):
+        self.hip, self.saved, self.records = hip_mod, {}, []
+
+    def wrap(self, name, describe):
+        """describe(args, kwargs, result) -> dict (or None to skip the call)"""
+        orig = getattr(self.hip, name)
+        self.saved[name] = orig
+
+        def timed(*a, **k):
+            info = describe(a, k)
+            if info is None:
+                return orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            self.records.append((name, info, e0, e1))
+            return r
+
+        setattr(self.hip, name, timed)
+
+    def remove(self):
+        for n, f in self.saved.items():
+            setattr(self.hip, n, f)
+        self.saved = {}
+
+    def results(self):
+        return [(n, info, e0.elapsed_time(e1)) for n, info, e0, e1 in self.records]
+
+
+def _bank_describe(a, k):
+    x, K, C = a[0], a[2], a[3]
+    return {} if tuple(x.shape) + (C, K) == BANK_SHAPE else None
+
+
+def dominant_kernel_roofline(bank_ms):
+    """The dominant GEMM-shaped launch of the step -- the postnet conv bank forward, one ft_gemm_rows_b3_kernel<2,2>
+    launch (M = 32*842 rows, 8 members k=1..8, Cin 80 -> 256: 2*B*(T+1)*80*256*36 FLOP)."""
     B, T, Cin, C, K = BANK_SHAPE
-    ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+    ms = sum(bank_ms) / max(len(bank_ms), 1)
     flops = 2.0 * B * (T + 1) * Cin * C * (K * (K + 1) // 2)
-    ach = flops / (ms * 1e-3) / 1e12
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     b3 = os.environ.get('FT_GEMM_B3', '1') != '0'
-    out = {'bound': 'mfma',
-           'kernel': ('ft_gemm_rows_b3_kernel<2,2>' if b3 else 'ft_gemm_rows_kernel<2,2,NT>') + ' (postnet conv bank fwd)',
+    kernel = 'ft_gemm_rows_b3_kernel<2,2>' if b3 else 'ft_gemm_rows_kernel<2,2,NT>'
+    out = {'bound': 'mfma', 'kernel': kernel + ' (postnet conv bank fwd)',
            'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-           # HBM-side bytes per launch from the PMC counters (profiles/r01e_pmc_bank_fwd.txt: FETCH_SIZE x 2 (gfx950
-           # correction for 16-B-per-lane reads) + WRITE_SIZE, separate rocprofv3 --pmc passes); algorithmic bytes 232 MB
-           'traffic': 401.6e6, 'traffic_unit': 'B/launch', 'algorithmic_bytes': 232.2e6,
-           'launch_ms': round(ms, 4), 'launches_timed': len(events), 'flops_per_launch': flops}
+           'launch_ms': round(ms, 4), 'launches_timed': len(bank_ms), 'flops_per_launch': flops,
+           'algorithmic_bytes': 4.0 * (B * (T + 1) * Cin + K * (K + 1) // 2 * Cin * C + B * (T + 1) * K * C),
+           'traffic': None, 'traffic_unit': 'B/launch', 'traffic_source': None}
+    # HBM-side bytes per launch: NOT measured in this run (PMC collection needs its own rocprofv3 passes); taken from
+    # the committed summary of those passes if it describes this kernel, else left null
+    try:
+        t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+        if t.get('kernel', '').startswith(kernel.split('<')[0]) and tuple(t.get('shape', ())) == BANK_SHAPE:
+            out['traffic'] = t['traffic_bytes_per_launch']
+            out['traffic_source'] = TRAFFIC_FILE + ' (offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 ' \
+                                                   'read correction)'
+    except (OSError, ValueError, KeyError):
+        pass
     if b3:
         # fp32 work executed on the bf16 matrix pipe: every fp32 product = 6 bf16 MFMA products of an exact 3-way
         # operand split, fp32 accumulation.  `achieved` stays the ALGORITHMIC fp32 rate (priced against the fp32 MFMA
@@ -63,21 +116,99 @@ def dominant_kernel_roofline(events):
     return out
 
 
-def cpu_baseline(model_cfg, train_cfg):
-    """Oracle (CPU port of the reference train step) on a bounded sample: B=2 items of the same shape."""
-    from oracle import ft_oracle as O       # checker / baseline leg only
+def family_rooflines(recs, steps, batch, step_ms):
+    """Per-step totals of the recurrence launches (time-dominant family) and of the LengthRegulator expansion."""
+    B = int(batch['x'].shape[0])
+    trunk = {'ms': 0.0, 'flop': 0.0, 'dep_steps': 0, 'launches': 0}
+    side = {'ms': 0.0, 'flop': 0.0, 'dep_steps': 0, 'launches': 0}
+    lr_ms, lr_bytes = 0.0, 0.0
+    for name, info, ms in recs:
+        if name == 'lr_expand':
+            lr_ms += ms
+            lr_bytes += info['bytes']
+            continue
+        acc = side if info['T'] <= int(batch['x'].shape[1]) and info['H'] <= 128 else trunk
+        acc['ms'] += ms
+        acc['flop'] += info['flop']
+        acc['dep_steps'] += info['T']
+        acc['launches'] += 1
+    out = []
+    for tag, acc in (('trunk (prenet GRU-256, LSTM-512, postnet GRU-128; the step\'s critical stream)', trunk),
+                     ('predictors (3 x GRU, side stream, overlapped)', side)):
+        if not acc['launches']:
+            continue
+        ms, tf = acc['ms'] / steps, acc['flop'] / steps / (acc['ms'] / steps * 1e-3) / 1e12
+        out.append({'family': 'persistent recurrences, ' + tag, 'bound': 'latency (cross-CU hand-off per dependent step)',
+                    'kernels': 'ft_rnn_fwd_persist_kernel / ft_rnn_bwd_persist_kernel / ft_rnn_bwd_rs_kernel',
+                    'ms_per_step': round(ms, 3), 'share_of_step': round(ms / step_ms, 3),
+                    'launches_per_step': acc['launches'] // steps, 'dependent_steps': acc['dep_steps'] // steps,
+                    'us_per_dependent_step': round(ms * 1e3 / (acc['dep_steps'] / steps), 3),
+                    'achieved': round(tf, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
+    if lr_ms > 0:
+        tbs = lr_bytes / (lr_ms * 1e-3) / 1e12
+        out.append({'family': 'LengthRegulator expand (ft_lr_expand_kernel)', 'bound': 'hbm',
+                    'ms_per_step': round(lr_ms / steps, 4), 'bytes_per_launch': lr_bytes / steps,
+                    'achieved': round(tbs * 1e3, 1), 'peak': HBM_PEAK_TBS * 1e3, 'unit': 'GB/s',
+                    'frac': round(tbs / HBM_PEAK_TBS, 4)})
+    return out
+
+
+def install_family_probes(probes, batch):
+    lens_sum = float(batch['mel_len'].sum())
+
+    def rnn(G, has_lens):
+        def d(a, k):
+            # gru_fwd(xp, ..., H, save) / gru_bwd(dout, out, gates, whhT_f, whhT_r, H) / lstm_fwd(xp, ..., lens, H, save)
+            # / lstm_bwd(dout, raw, cst, gates, whhT_f, whhT_r, lens, H): first tensor is time-major [T,B,*]
+            T, Bq = int(a[0].shape[0]), int(a[0].shape[1])
+            H = [v for v in a if isinstance(v, int)][0]
+            lens = next((v for v in a if torch.is_tensor(v) and v.dtype == torch.int64), None) if has_lens else None
+            valid = lens_sum if lens is not None else float(Bq * T)
+            return {'T': T, 'H': H, 'flop': 2.0 * valid * 2 * G * H * H}
+        return d
+
+    probes.wrap('gru_fwd', rnn(3, False))
+    probes.wrap('gru_bwd', rnn(3, False))
+    probes.wrap('lstm_fwd', rnn(4, True))
+    probes.wrap('lstm_bwd', rnn(4, True))
+
+    def lr(a, k):
+        x, cum, Tm = a[0], a[1], a[2]
+        Bq, Tx, C = x.shape
+        # algorithmic bytes (SURVEY 8d): one 4*C-byte row read per valid token + one written per output frame (B x Tm)
+        return {'bytes': 4.0 * C * (float(batch['x_len'].sum()) + Bq * Tm)}
+
+    probes.wrap('lr_expand', lr)
+
+
+def cpu_baseline(model_cfg, train_cfg, budget_s):
+    """The reference step on stock fused torch CPU ops (oracle/ft_torch_cpu.py), SAME bs=32 seed-0 batch as the GPU
+    run, all host cores: a B=2 warm-up step (thread pools, allocator), then whole bs=32 steps while they fit the
+    budget (at least one)."""
+    from oracle import ft_torch_cpu as C        # baseline leg only
+    from forwardtacotron_amd import data
     from forwardtacotron_amd.model import ForwardTacotron
     torch.manual_seed(0)
     m = ForwardTacotron(**model_cfg)
     P = {k: v.clone() for k, v in m.state_dict().items()}
-    batch = O.synthetic_batch(B=2, Tmax=128, n_mels=model_cfg['n_mels'], seed=0)
+    tr = C.CpuTrainer(P, model_cfg, train_cfg, lr=5e-5)
+    tr.step(data.synthetic_batch(B=2, Tmax=128, n_mels=model_cfg['n_mels'], seed=1))
+    batch = data.synthetic_batch(B=32, Tmax=128, n_mels=model_cfg['n_mels'], seed=0)
     n_frm = int(batch['mel_len'].sum())
-    t0 = time.time()
-    O.train_step(P, {}, batch, model_cfg, train_cfg, lr=5e-5, step_count=1)
-    dt = time.time() - t0
+    times = []
+    t_all = time.time()
+    while not times or (len(times) < 3 and time.time() - t_all + max(times) < budget_s):
+        t0 = time.time()
+        tr.step(batch)
+        times.append(time.time() - t0)
+    dt = sum(times) / len(times)
     return {'value': round(n_frm / dt, 1), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'1 train step, B=2 of the bs=32 workload ({n_frm} frames, {dt:.1f} s), '
-                      f'oracle/ft_oracle.py on {os.cpu_count()} host cpus'}
+            'sample': f'{len(times)} full train step(s) of the SAME bs=32 seed-0 batch ({n_frm} frames, '
+                      f'{dt:.1f} s/step) after a B=2 warm-up step; oracle/ft_torch_cpu.py (stock fused torch CPU ops: '
+                      f'conv1d, batch_norm, _VF.gru/lstm packed, autograd, Adam), torch threads '
+                      f'{torch.get_num_threads()}, nproc {os.cpu_count()}',
+            'step_seconds': [round(t, 2) for t in times]}
 
 
 def main():
@@ -85,6 +216,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--family-steps', type=int, default=3, help='instrumented steps after the timed region (rank 0)')
+    ap.add_argument('--cpu-budget', type=float, default=120.0, help='seconds of CPU baseline work (N=1, rank 0)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -111,34 +244,34 @@ def main():
     from forwardtacotron_amd import data
     from forwardtacotron_amd.model import ForwardTacotron
     from forwardtacotron_amd.trainer import TrainStep
+    from forwardtacotron_amd import _lib as _ftlib, hip as _hip
 
     model_cfg = dict(data.SINGLESPEAKER_MODEL)
     train_cfg = dict(data.SINGLESPEAKER_TRAIN)
-    torch.manual_seed(0)                      # identical initial weights on every rank
-    model = ForwardTacotron(**model_cfg).to(device)
-    ts = TrainStep(model, lr=5e-5, train_cfg=train_cfg)
     batch = data.to_device(data.synthetic_batch(B=32, Tmax=128, n_mels=80, seed=rank), device)
     n_frm = int(batch['mel_len'].sum())
     n_tok = int(batch['x_len'].sum())
     dur0 = batch['dur'].clone()
-
-    def one_step():
-        batch['dur'].copy_(dur0)              # the LengthRegulator clamps dur in place
-        return ts.step(batch)
-
-    from forwardtacotron_amd import _lib as _ftlib, hip as _hip
-    probe = {'shape': BANK_SHAPE, 'events': []}
     if rehearsal and world > 1:
         # several ranks share one GPU here: their persistent grids cannot all be co-resident
         _ftlib.query('ft_rnn_set_persistent', 0)
 
-    def measure():
+    def build():
+        torch.manual_seed(0)                  # identical initial weights on every rank
+        model = ForwardTacotron(**model_cfg).to(device)
+        return TrainStep(model, lr=5e-5, train_cfg=train_cfg)
+
+    def measure(ts):
         """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize."""
+        def one_step():
+            batch['dur'].copy_(dur0)          # the LengthRegulator clamps dur in place
+            return ts.step(batch)
+
         for _ in range(args.warmup):
             one_step()
-        probe['events'] = []
+        probes = Probes(_hip)
         if rank == 0:
-            _hip.bank_probe = probe           # two event records per step: no synchronisation, no extra launches
+            probes.wrap('conv_bank_fwd', _bank_describe)      # two event records per step
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -151,25 +284,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        _hip.bank_probe = None
+        probes.remove()
+        bank_ms = [ms for _, _, ms in probes.results()]
+        fam = []
         try:
-            _hip.check_rnn_status()           # raises if a persistent recurrence hit its spin bound
+            _hip.check_rnn_status()           # raises if a persistent recurrence hit its spin bound (sticky word)
             ok = 1.0
         except _ftlib.FtError:
             ok = 0.0
+        if ok and world == 1 and args.family_steps > 0:      # (extra steps on one rank only would hang the all-reduce)
+            fp = Probes(_hip)
+            install_family_probes(fp, batch)
+            for _ in range(args.family_steps):
+                one_step()
+            torch.cuda.synchronize()
+            fp.remove()
+            fam = family_rooflines(fp.results(), args.family_steps, batch, elapsed / args.steps * 1e3)
         flag = torch.tensor([ok], device=device)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return elapsed, o, bool(flag.item() > 0)
+        return elapsed, o, bool(flag.item() > 0), bank_ms, fam
 
-    dt, out, rnn_ok = measure()
+    dt, out, rnn_ok, bank_ms, fam = measure(build())
     rnn_persistent = not (rehearsal and world > 1)
     if not rnn_ok:
-        # a persistent recurrence timed out on some rank (its workgroups were not co-resident, e.g. under heavy
-        # contention): that run is invalid -- switch every rank to the per-timestep kernels and measure again
+        # a persistent recurrence timed out on some rank: the device skipped every update from then on, so the run
+        # timed something else -- switch every rank to the per-timestep kernels, rebuild model and trainer from the
+        # seed and measure again
         _ftlib.query('ft_rnn_set_persistent', 0)
         rnn_persistent = False
-        dt, out, rnn_ok = measure()
+        dt, out, rnn_ok, bank_ms, fam = measure(build())
         if not rnn_ok:
             raise SystemExit('bench.py: recurrence status still bad with the per-step kernels')
     stats = torch.tensor([dt, float(n_frm), float(n_tok)], device=device, dtype=torch.float64)
@@ -188,10 +332,13 @@ def main():
         ms = dt / args.steps * 1e3
         value = tot_frm * args.steps / dt
         step_tflops = data.train_flops(tot_tok, tot_frm) / (dt / args.steps) / 1e12
-        roof = dominant_kernel_roofline(probe['events'])
+        roof = dominant_kernel_roofline(bank_ms)
+        roof['families'] = fam
         roof['step'] = {'algorithmic_tflops': round(step_tflops, 2),
                         'frac_of_f32_mfma_peak': round(step_tflops / (F32_MFMA_PEAK_TFLOPS * world), 4),
+                        'frac_of_bf16_dense_peak': round(step_tflops / (BF16_MFMA_PEAK_TFLOPS * world), 4),
                         'flop_per_valid_frame': 64.5e6}
+        pers, refused = _hip.rnn_counters()
         line = {
             'metric': 'mel_frames_per_sec_train_step', 'value': round(value, 1), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
@@ -204,10 +351,11 @@ def main():
                                      'MFMA, 128x128-tile GEMMs as exact 3-way bf16 splits on bf16 MFMA (fp32-accurate: '
                                      'same parity bars, FT_GEMM_B3=0 switches it off)'},
             'per_gpu': round(value / world, 1), 'loss': round(loss, 5), 'rnn_persistent': rnn_persistent,
+            'rnn_launches': {'persistent': pers, 'refused_admission': refused},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(model_cfg, train_cfg)
+            line['cpu_baseline'] = cpu_baseline(model_cfg, train_cfg, args.cpu_budget)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

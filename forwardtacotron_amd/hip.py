@@ -302,20 +302,9 @@ def conv_bank_fwd(x: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, relu: b
     B, T, Cin = x.shape
     assert wp_all.numel() == C * Cin * K * (K + 1) // 2
     y = torch.empty(B, Tout, K * C, device=x.device, dtype=x.dtype)
-    probe = bank_probe if bank_probe is not None and bank_probe['shape'] == (B, T, Cin, C, K) else None
-    if probe is not None:       # bench.py: HIP events around THIS launch, on the stream it is launched on
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     _lib.call('ft_conv_bank_fwd', _p(x), Cin, _p(wp_all), _p(scale), _p(shift), _p(y), B, T, Cin, C, K, Tout,
               int(relu), _stream())
-    if probe is not None:
-        e1.record()
-        probe['events'].append((e0, e1))
     return y
-
-
-# set by bench.py to {'shape': (B, T, Cin, C, K), 'events': []} while it times the dominant GEMM launch inside the steps
-bank_probe = None
 
 
 def conv_pack_weight_t(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
