@@ -182,10 +182,13 @@ def install_family_probes(probes, batch):
     probes.wrap('lr_expand', lr)
 
 
-def cpu_baseline(model_cfg, train_cfg, budget_s):
+def cpu_baseline(model_cfg, train_cfg, budget_s, threads):
     """The reference step on stock fused torch CPU ops (oracle/ft_torch_cpu.py), SAME bs=32 seed-0 batch as the GPU
-    run, all host cores: a B=2 warm-up step (thread pools, allocator), then whole bs=32 steps while they fit the
-    budget (at least one)."""
+    run: a B=2 warm-up step (thread pools, allocator), then whole bs=32 steps while they fit the budget (at least
+    one).  Threads: the step is ~3,650 dependent recurrence timesteps of small matmuls plus their autograd, which does
+    not scale with cores -- measured on the MI355X host (256 cpus): 128 torch threads 226 s/step, 8 threads (build
+    container) 51 s/step; the default is 16 threads = one GPU's share of the host, stated in `cores`."""
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
     from oracle import ft_torch_cpu as C        # baseline leg only
     from forwardtacotron_amd import data
     from forwardtacotron_amd.model import ForwardTacotron
@@ -218,6 +221,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--family-steps', type=int, default=3, help='instrumented steps after the timed region (rank 0)')
     ap.add_argument('--cpu-budget', type=float, default=120.0, help='seconds of CPU baseline work (N=1, rank 0)')
+    ap.add_argument('--cpu-threads', type=int, default=16, help='torch threads of the CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -355,7 +359,7 @@ def main():
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(model_cfg, train_cfg, args.cpu_budget)
+            line['cpu_baseline'] = cpu_baseline(model_cfg, train_cfg, args.cpu_budget, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -12,6 +12,15 @@
 //   consumer: 16 lanes of wave 0 poll the 16 shards of the group with sc1 loads until each holds
 //             step * (#producing waves of the shard); workgroup barrier; sc1 16-B loads of the operand rows.
 //   (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", row "each storing wave for itself".)
+// XCD-LOCAL mode.  The agent-scope hand-off above costs two fabric round trips per step (write-through stores drop
+// the line from the XCD's L2; counters live at the memory side).  When the grid is laid out so that every workgroup of
+// a (direction, batch group) group sits in ONE XCD slot (blockIdx % 8 equal), the group's hand-off can stay inside
+// that XCD's L2, which IS coherent for its own CUs: plain stores (the line stays in L2) -> the wave's s_waitcnt
+// vmcnt(0) -> a plain store of (step + 1) to the wave's own flag word; consumers poll the flag words and read the
+// operands with L1-bypassing (sc1) loads, served by the L2.  Placement is NOT assumed (HIP promises none): every
+// workgroup publishes its HW_REG_XCC_ID with the agent-scope protocol during step 0; at step 1 -- still on the
+// agent-scope protocol -- every workgroup of a group sees the same 'all ids equal' verdict and the group switches to
+// the local protocol from then on, or stays on the agent-scope one for the whole launch.  Any placement is correct.
 // Step s reads parity (s-1)&1 and writes parity s&1; a workgroup can only be one step ahead of the slowest producer it
 // depends on, so two parities suffice.  Every spin is bounded: on timeout the workgroup raises the device's STICKY
 // fault word (g_rnn_fault: no launch ever clears it, only ft_rnn_status does) and leaves; all others then time out at
@@ -42,6 +51,8 @@ constexpr int NSH = 16;                // arrival-counter shards per group
 constexpr int CSTRIDE = 32;            // one counter per 128-B line
 constexpr unsigned MAX_SPINS_DEFAULT = 1u << 18;
 constexpr int MB = 16;                 // batch rows per workgroup
+constexpr int NFLAG = 256;             // XCD-local mode: flag words per group (one per signalling wave)
+constexpr int NXCC = 64;               // published XCC ids per group (one per workgroup)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -84,10 +95,12 @@ struct Geom {
   int xcd_aware, sig_per_wave;
   int xcd_off;                         // group-aligned placement: physical XCD of logical slot 0
   unsigned max_spins;                  // bound of every arrival poll (ft_rnn_set_max_spins; tests force timeouts with it)
+  int local_ok;                        // groups are XCD-slot aligned: the XCD-local hand-off may be used if placement agrees
 };
 
 // sticky per-device fault word (one 128-B line of its own): set by any workgroup whose poll ran out, cleared only by
-// ft_rnn_status; read on the device by the optimizer kernels (ft_optim.hip) through ft_rnn_fault_word()
+// ft_rnn_status; read on the device by the optimizer kernels (ft_optim.hip) through ft_rnn_fault_word().  Words 8 / 9
+// of the line count the groups that ran XCD-local / on the agent-scope protocol (ft_rnn_mode_counts).
 __device__ unsigned g_rnn_fault[32];
 
 __device__ __forceinline__ float4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -113,6 +126,38 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned step
     }
   }
   return __all(ok);
+}
+
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xFu;
+}
+
+// XCD-local mode: wave 0 waits until the n flag words of the group (n % 4 == 0, n <= NFLAG) all hold >= step; the
+// loads bypass L1 (sc1) and are served by the XCD's L2, where the producers' plain flag stores land
+__device__ __forceinline__ bool wait_flags(const unsigned* f, unsigned step, int n, int lane, unsigned max_spins) {
+  bool ok = max_spins != 0;              // 0 = fault injection
+  if (4 * lane < n) {
+    unsigned spins = 0;
+    while (ok) {
+      const unsigned a = __hip_atomic_load(f + 4 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned b = __hip_atomic_load(f + 4 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned c = __hip_atomic_load(f + 4 * lane + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned d = __hip_atomic_load(f + 4 * lane + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (min(min(a, b), min(c, d)) >= step) break;
+      if (++spins > max_spins) ok = false;
+    }
+  }
+  return __all(ok);
+}
+
+// step 1, wave 0, after the agent-scope arrival wait: did every workgroup of the group report my XCC id?
+__device__ __forceinline__ bool same_xcd(const unsigned* ids, int nchunks, unsigned mine, int lane) {
+  bool same = true;
+  for (int i = lane; i < nchunks; i += 64)
+    same &= __hip_atomic_load(ids + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine;
+  return __all(same);
 }
 
 // XCD-aware decode of the 1-D grid: dispatch is round-robin over the 8 XCDs, so XCD x runs work items
@@ -151,6 +196,16 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
   unsigned* mycnt = cnt + (long)grp * NSH * CSTRIDE;
   const int nprod = (geo.sig_per_wave ? 2 : 1) * geo.nchunks;             // signalling waves per group
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xb_bytes, 0x00020000);
+  // XCD-local mode state (file header): flag words and published XCC ids of this group
+  unsigned* myflags = cnt + (long)2 * geo.nbg * NSH * CSTRIDE + (long)grp * NFLAG;
+  unsigned* myxcc = cnt + (long)2 * geo.nbg * (NSH * CSTRIDE + NFLAG) + (long)grp * NXCC;
+  const unsigned my_xcc = xcc_id() + 1u;
+  __shared__ int s_local;
+  bool local = false;
+  if (tid == 0) {
+    s_local = 0;
+    __hip_atomic_store(myxcc + chunk, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // drained before wave 0's first signal
+  }
 
   // ---- resident W_hh fragments of this wave: tile nt, column l15 -> (gate, unit) = ((nt*16+l15)/8, (nt*16+l15)%8)
   const int ngroups = H / 16;
@@ -217,13 +272,22 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     float4 aw[B3 ? BCH : 1][2];
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+        const bool ok = local ? wait_flags(myflags, (unsigned)s, nprod, lane, geo.max_spins)
+                              : wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+        if (s == 1 && ok && geo.local_ok) {
+          const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
+          if (lane == 0) s_local = same;
+        }
         if (lane == 0) s_ok = ok;
       }
       __syncthreads();
       if (!s_ok) {
         if (tid == 0) atomicExch(fault, 1u);
         return;
+      }
+      if (s == 1) {
+        local = s_local != 0;
+        if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);      // statistics: groups per mode
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
       if constexpr (!B3) {
@@ -305,14 +369,19 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       hprev = hnew;
       // exchange block [2*chunk + jq][16][4] of parity s&1 (write-through), before anything else
       float* xw = xb + (long)(s & 1) * par_floats + base_floats + (((long)2 * chunk + jq) * MB + ci) * 4 + jj;
-      __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (local) __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain: stays in the XCD's L2
+      else __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // write-through (sc1)
     }
     if (geo.sig_per_wave) {
       if (sthr) {                                          // waves 0 and 1, wave-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-          __hip_atomic_fetch_add(mycnt + ((2 * chunk + jq) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+          if (local)
+            __hip_atomic_store(myflags + 2 * chunk + jq, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          else
+            __hip_atomic_fetch_add(mycnt + ((2 * chunk + jq) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -360,6 +429,15 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
   unsigned* mycnt = cnt + (long)grp * NSH * CSTRIDE;
   const int nprod = (geo.sig_per_wave ? 4 : 1) * geo.nchunks;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xb_bytes, 0x00020000);
+  unsigned* myflags = cnt + (long)2 * geo.nbg * NSH * CSTRIDE + (long)grp * NFLAG;      // XCD-local mode (file header)
+  unsigned* myxcc = cnt + (long)2 * geo.nbg * (NSH * CSTRIDE + NFLAG) + (long)grp * NXCC;
+  const unsigned my_xcc = xcc_id() + 1u;
+  __shared__ int s_local;
+  bool local = false;
+  if (threadIdx.x == 0) {
+    s_local = 0;
+    __hip_atomic_store(myxcc + chunk, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- resident W_hh^T fragments: column l15 = unit u0+l15 ; K groups [g0,g1)
   const float* brow = a.whhT[d] + (long)(u0 + l15) * K;
@@ -432,13 +510,22 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
     float4 aw[B3 ? BW : 1][2];
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+        const bool ok = local ? wait_flags(myflags, (unsigned)s, nprod, lane, geo.max_spins)
+                              : wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+        if (s == 1 && ok && geo.local_ok) {
+          const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
+          if (lane == 0) s_local = same;
+        }
         if (lane == 0) s_ok = ok;
       }
       __syncthreads();
       if (!s_ok) {
         if (tid == 0) atomicExch(fault, 1u);
         return;
+      }
+      if (s == 1) {
+        local = s_local != 0;
+        if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);      // statistics: groups per mode
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
       if constexpr (!B3) {
@@ -512,16 +599,21 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float v = (G == 3 && g == 2) ? dgh2 : dgx[g];
-        __hip_atomic_store(xw + (((long)(g * H + u0) / 4 + j4) * MB + ci) * 4 + jj, v, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        float* q = xw + (((long)(g * H + u0) / 4 + j4) * MB + ci) * 4 + jj;
+        if (local) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (geo.sig_per_wave) {
       if (sthr) {                                          // waves 0..3, wave-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-          __hip_atomic_fetch_add(mycnt + ((4 * chunk + j4) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+          if (local)
+            __hip_atomic_store(myflags + 4 * chunk + j4, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          else
+            __hip_atomic_fetch_add(mycnt + ((4 * chunk + j4) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -588,6 +680,15 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
   unsigned* mycnt = cnt + (long)grp * NSH * CSTRIDE;
   const int nprod = NW * P;                           // every wave signals its own stores
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xb_bytes, 0x00020000);
+  unsigned* myflags = cnt + (long)2 * geo.nbg * NSH * CSTRIDE + (long)grp * NFLAG;      // XCD-local mode (file header)
+  unsigned* myxcc = cnt + (long)2 * geo.nbg * (NSH * CSTRIDE + NFLAG) + (long)grp * NXCC;
+  const unsigned my_xcc = xcc_id() + 1u;
+  __shared__ int s_local;
+  bool local = false;
+  if (threadIdx.x == 0) {
+    s_local = 0;
+    __hip_atomic_store(myxcc + chunk, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- resident W_hh rows of this workgroup's units, as B fragments: tile nt = consumer chunk wave*NT + nt, column
   //      l15 = output unit n; local k = g*16 + j  <->  W_hh[g*H + u0 + j][n] = whhT[n][g*H + u0 + j]
@@ -647,13 +748,22 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
     float rec = 0.f;
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+        const bool ok = local ? wait_flags(myflags, (unsigned)s, nprod, lane, geo.max_spins)
+                              : wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+        if (s == 1 && ok && geo.local_ok) {
+          const bool same = same_xcd(myxcc, P, my_xcc, lane);
+          if (lane == 0) s_local = same;
+        }
         if (lane == 0) s_ok = ok;
       }
       __syncthreads();
       if (!s_ok) {
         if (tid == 0) atomicExch(fault, 1u);
         return;
+      }
+      if (s == 1) {
+        local = s_local != 0;
+        if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);      // statistics: groups per mode
       }
       if (sthr) {       // the P partials of (row ci, unit cj), summed in producer order
         const long rbase = (long)((s - 1) & 1) * par_floats + base_floats + (long)chunk * P * 256 + tid;
@@ -716,13 +826,19 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
         const int cons = wave * NT + nt;
         if (cons < P) {
           u32x4 v = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (unsigned)((wbase + (long)cons * P * 256) * 4), 0, 16);
+          const unsigned off = (unsigned)((wbase + (long)cons * P * 256) * 4);
+          if (local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);       // plain: stays in the XCD's L2
+          else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);            // write-through (sc1)
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
-        __hip_atomic_fetch_add(mycnt + ((NW * chunk + wave) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) {
+        if (local)
+          __hip_atomic_store(myflags + NW * chunk + wave, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else
+          __hip_atomic_fetch_add(mycnt + ((NW * chunk + wave) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (cact) {
       float* dx = a.dxp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
@@ -775,28 +891,30 @@ int device_cus() {
 struct PersistWs {
   float* xb;
   unsigned* cnt;
-  size_t cnt_bytes, xb_bytes, total_bytes;
+  size_t sync_bytes, xb_bytes, total_bytes;
 };
-// workspace = [arrival counters | exchange buffer], zeroed per call from the allocation's start (the fault word is
-// NOT in here: it is the device-global g_rnn_fault, which launches never touch)
+// workspace = [arrival counters | flag words | XCC ids | exchange buffer]; the sync region (and, for the all-gather
+// forms, the exchange buffer) is zeroed per call from the allocation's start (the fault word is NOT in here: it is the
+// device-global g_rnn_fault, which launches never touch)
+size_t sync_region_bytes(int ngrp) { return (size_t)ngrp * (NSH * CSTRIDE + NFLAG + NXCC) * sizeof(unsigned); }
 PersistWs carve_ws(void* ws, int ngrp, int K) {
   PersistWs p;
-  p.cnt_bytes = (size_t)ngrp * NSH * CSTRIDE * sizeof(unsigned);
+  p.sync_bytes = sync_region_bytes(ngrp);
   p.cnt = (unsigned*)ws;
   p.xb_bytes = (size_t)2 * ngrp * (K / 4) * MB * 4 * sizeof(float);
-  p.xb = (float*)((char*)ws + p.cnt_bytes);
-  p.total_bytes = p.cnt_bytes + p.xb_bytes;
+  p.xb = (float*)((char*)ws + p.sync_bytes);
+  p.total_bytes = p.sync_bytes + p.xb_bytes;
   return p;
 }
 
 // reduce-scatter backward: xb[parity][group][consumer][producer][256]
 PersistWs carve_ws_rs(void* ws, int ngrp, int nchunks) {
   PersistWs p;
-  p.cnt_bytes = (size_t)ngrp * NSH * CSTRIDE * sizeof(unsigned);
+  p.sync_bytes = sync_region_bytes(ngrp);
   p.cnt = (unsigned*)ws;
   p.xb_bytes = (size_t)2 * ngrp * nchunks * nchunks * 256 * sizeof(float);
-  p.xb = (float*)((char*)ws + p.cnt_bytes);
-  p.total_bytes = p.cnt_bytes + p.xb_bytes;
+  p.xb = (float*)((char*)ws + p.sync_bytes);
+  p.total_bytes = p.sync_bytes + p.xb_bytes;
   return p;
 }
 
@@ -812,53 +930,77 @@ int current_device() {
 
 // ---- admission: every workgroup of a persistent grid spins until the whole grid is resident, so two such grids on
 // different streams (trunk recurrence on the step's main stream, a predictor's on the side stream) must BOTH fit
-// beside each other, or each could hold the CUs the other is waiting for.  A launch is admitted only while the
-// CU share of the persistent grids still in flight on this device (one event per launch, retired by query) plus its
-// own stays within the chip; a refused launch runs the per-step kernels (always safe).  Non-persistent kernels (GEMMs,
-// RCCL) only delay residency: they finish without waiting for us.
+// beside each other, or each could hold the CUs the other is waiting for.  Workgroup i goes to XCD slot i % 8 and must
+// find room on a CU of THAT XCD, and which physical XCD a launch's slot 0 is cannot be known, so the budget is per XCD
+// for the worst case that every concurrent launch puts its fullest slot on the same XCD:
+//     demand d = (workgroups of the fullest XCD slot) / (32 CUs x workgroups per CU, capped at 2)
+// Launches of ONE stream execute in order (at most one of them resident), but the host enqueues far ahead of the
+// device, so "unfinished" launches pile up per stream: a launch on stream s is admitted while
+//     d + sum over the OTHER streams of (the largest d among that stream's unfinished launches) <= 0.75
+// (a quarter is kept back: a CU left with room for half a workgroup helps nobody), or -- with nothing unfinished on
+// other streams -- while d <= 1.  ft_rnn_note_join tells the bookkeeping that a stream has waited for another (the
+// joined stream's earlier launches then precede everything the waiting stream does and no longer count against it).
+// One event per launch, retired by query; a refused launch runs the per-step kernels (always safe).  Non-persistent
+// kernels (GEMMs, RCCL) only delay residency: they finish without waiting for us.
 struct Flight {
   hipEvent_t ev;
-  double cus;
+  hipStream_t stream;
+  double d;
+  std::vector<hipStream_t> joined_by;      // streams that waited for `stream` after this launch was enqueued
 };
 std::mutex g_adm_mu;
 std::vector<Flight> g_flights[MAX_DEV];
 std::vector<hipEvent_t> g_ev_pool[MAX_DEV];
 
 template <typename KernelT>
-double grid_cu_share(KernelT kernel, int block, long nblocks) {
+double xcd_demand(KernelT kernel, int block, int wgs_per_slot) {
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) return -1.0;
   if (per_cu > 2) per_cu = 2;      // stay well inside what the dispatcher really admits
-  return (double)nblocks / per_cu;
+  return (double)wgs_per_slot / (per_cu * (device_cus() / 8.0));
 }
 
-// true: admitted (call admitted_launch_done after the launch); false: does not fit beside what is in flight
-bool admit(double cus) {
-  if (cus < 0.0 || !ft_rnn_fault_word()) return false;
+// true: admitted (call admitted_launch_done after the launch); false: does not fit beside what other streams may run
+bool admit(double d, hipStream_t stream) {
+  if (d < 0.0 || !ft_rnn_fault_word()) return false;
   const int dev = current_device();
   std::lock_guard<std::mutex> lk(g_adm_mu);
   auto& fl = g_flights[dev];
-  double busy = 0.0;
   for (size_t i = 0; i < fl.size();) {
     if (hipEventQuery(fl[i].ev) == hipSuccess) {
       g_ev_pool[dev].push_back(fl[i].ev);
-      fl[i] = fl.back();
+      fl[i] = std::move(fl.back());
       fl.pop_back();
     } else {
-      busy += fl[i].cus;
       ++i;
     }
   }
   (void)hipGetLastError();         // hipErrorNotReady of a pending event is not an error
-  const double cap = (double)device_cus() * (env_int("FT_RNN_ADMIT_PCT", 100) / 100.0);
-  if (busy + cus > cap) {
-    ++g_n_refused;
-    return false;
+  auto counts = [&](const Flight& f) {
+    if (f.stream == stream) return false;
+    for (hipStream_t j : f.joined_by)
+      if (j == stream) return false;
+    return true;
+  };
+  double others = 0.0;             // sum over other streams of their largest unfinished demand
+  for (size_t i = 0; i < fl.size(); ++i) {
+    if (!counts(fl[i])) continue;
+    bool first = true;
+    double mx = 0.0;
+    for (size_t j = 0; j < fl.size(); ++j)
+      if (fl[j].stream == fl[i].stream && counts(fl[j])) {
+        if (j < i) first = false;
+        if (fl[j].d > mx) mx = fl[j].d;
+      }
+    if (first) others += mx;
   }
+  const double scale = env_int("FT_RNN_ADMIT_PCT", 100) / 100.0;
+  const bool fits = others == 0.0 ? d <= 1.0 * scale : d + others <= 0.75 * scale;
+  if (!fits) return false;
   return true;
 }
 
-void admitted_launch_done(double cus, hipStream_t stream) {
+void admitted_launch_done(double d, hipStream_t stream) {
   const int dev = current_device();
   std::lock_guard<std::mutex> lk(g_adm_mu);
   hipEvent_t ev;
@@ -869,37 +1011,59 @@ void admitted_launch_done(double cus, hipStream_t stream) {
     return;
   }
   (void)hipEventRecord(ev, stream);
-  g_flights[dev].push_back({ev, cus});
+  g_flights[dev].push_back({ev, stream, d, {}});
   ++g_n_persistent;
 }
 
-// 1-D grid = 8 x (work items per XCD): the decode hands XCD x the items [x*per, (x+1)*per).  Small layers (<= 64
-// workgroups, whole (direction, batch group) groups of <= 32 workgroups: the postnet's GRU-128, the predictors' GRU-64)
-// get per rounded up to whole groups, so that a group's hand-off stays inside ONE XCD (GRU-128: 2.49 -> 2.06 / 2.95 -> 2.50
-// us per step fwd / bwd); the surplus workgroups of the larger grid exit at once, and successive launches start on
-// different XCDs so that concurrent small recurrences (predictors beside the prenet) do not pile onto the same ones.
-// Larger layers keep the spread mapping: pinned to half of the XCDs they would have to wait for the CUs that the
-// weight-gradient GEMMs running beside them hold (measured in-step: +1.7 ms).
-int persist_grid(Geom& geo) {
+// Grid layout of a persistent launch.  The 1-D grid is 8 x per: the decode hands XCD slot x the work items
+// [x*per, (x+1)*per).  ALIGNED: per = whole (direction, batch group) groups, so that a group's hand-off stays inside
+// one XCD (the XCD-local protocol then applies; surplus workgroups of the larger grid exit at once); successive
+// launches start on different slots.  SPREAD: per = ceil(total / 8), groups straddle XCDs, agent-scope protocol only.
+// The aligned layout is tried first; if its (larger) per-XCD demand is not admitted, the spread one is.
+struct Layout {
+  int grid, per, xcd_off, aligned;
+};
+Layout layout_aligned(const Geom& geo) {
   static int rotor = 0;
-  int per = ft_cdiv(geo.total, 8);
-  geo.xcd_off = 0;
-  if (geo.xcd_aware && env_int("FT_RNN_XCDALIGN", 1) && geo.total <= 64 && geo.nchunks <= 32) {
-    const int ngroups = geo.total / geo.nchunks;
-    const int aligned = geo.nchunks * ft_cdiv(ngroups, 8);
-    if (aligned <= 32) {
-      per = aligned;
-      geo.xcd_off = rotor & 7;
-      rotor += ngroups < 8 ? ngroups : 8;
-    }
+  Layout l = {0, 0, 0, 0};
+  if (!geo.xcd_aware || !geo.sig_per_wave || !env_int("FT_RNN_XCDALIGN", 1) || geo.nchunks > NXCC) return l;
+  const int ngroups = geo.total / geo.nchunks;
+  l.per = geo.nchunks * ft_cdiv(ngroups, 8);
+  l.grid = 8 * l.per;
+  l.xcd_off = rotor & 7;
+  l.aligned = 1;
+  rotor += ngroups < 8 ? ngroups : 8;
+  return l;
+}
+Layout layout_spread(const Geom& geo) {
+  Layout l = {0, 0, 0, 0};
+  l.per = ft_cdiv(geo.total, 8);
+  l.grid = 8 * l.per;
+  return l;
+}
+
+// picks the layout, checks admission, fills geo; -1.0 = not admitted in any layout
+template <typename KernelT>
+double plan_launch(KernelT kernel, int block, Geom& geo, int& grid, hipStream_t stream) {
+  const Layout cand[2] = {layout_aligned(geo), layout_spread(geo)};
+  for (int i = 0; i < 2; ++i) {
+    if (cand[i].grid == 0) continue;
+    const double d = xcd_demand(kernel, block, cand[i].per);
+    if (d > 1.0 || !admit(d, stream)) continue;
+    grid = cand[i].grid;
+    geo.xcd_off = cand[i].xcd_off;
+    geo.local_ok = cand[i].aligned && env_int("FT_RNN_LOCAL", 1);
+    return d;
   }
-  return 8 * per;
+  ++g_n_refused;
+  return -1.0;
 }
 
 template <int G, int NW, bool B3>
-int launch_fwd_persist(const RnnFwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  const double cus = grid_cu_share(ft_rnn_fwd_persist_kernel<G, NW, B3>, NW * 64, geo.total);
-  if (!admit(cus)) return -1;
+int launch_fwd_persist(const RnnFwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
+  int grid = 0;
+  const double cus = plan_launch(ft_rnn_fwd_persist_kernel<G, NW, B3>, NW * 64, geo, grid, stream);
+  if (cus < 0.0) return -1;
   (void)hipMemsetAsync(p.cnt, 0, p.total_bytes, stream);
   hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
                      ft_rnn_fault_word(), (unsigned)p.xb_bytes);
@@ -924,19 +1088,21 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.max_spins = g_max_spins;
   PersistWs p = carve_ws(ws, 2 * geo.nbg, H);
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
-  const int grid = persist_grid(geo);
+  geo.xcd_off = 0;
+  geo.local_ok = 0;
   a.s = 0;
   if (H % 32 == 0 && ft_cdiv(H / 32, NW) <= GCH / 2 && env_int("FT_RNN_B3", 1))     // matmul on the bf16 pipe (exact split)
-    return NW == 8 ? launch_fwd_persist<G, 8, true>(a, geo, p, grid, stream)
-                   : launch_fwd_persist<G, 4, true>(a, geo, p, grid, stream);
-  return NW == 8 ? launch_fwd_persist<G, 8, false>(a, geo, p, grid, stream)
-                 : launch_fwd_persist<G, 4, false>(a, geo, p, grid, stream);
+    return NW == 8 ? launch_fwd_persist<G, 8, true>(a, geo, p, stream)
+                   : launch_fwd_persist<G, 4, true>(a, geo, p, stream);
+  return NW == 8 ? launch_fwd_persist<G, 8, false>(a, geo, p, stream)
+                 : launch_fwd_persist<G, 4, false>(a, geo, p, stream);
 }
 
 template <int G, int NW, int GW, bool B3>
-int launch_bwd_persist(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  const double cus = grid_cu_share(ft_rnn_bwd_persist_kernel<G, NW, GW, B3>, NW * 64, geo.total);
-  if (!admit(cus)) return -1;
+int launch_bwd_persist(const RnnBwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
+  int grid = 0;
+  const double cus = plan_launch(ft_rnn_bwd_persist_kernel<G, NW, GW, B3>, NW * 64, geo, grid, stream);
+  if (cus < 0.0) return -1;
   (void)hipMemsetAsync(p.cnt, 0, p.total_bytes, stream);
   hipLaunchKernelGGL((ft_rnn_bwd_persist_kernel<G, NW, GW, B3>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
                      ft_rnn_fault_word(), (unsigned)p.xb_bytes);
@@ -945,11 +1111,12 @@ int launch_bwd_persist(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p,
 }
 
 template <int G, int NW, int NT>
-int launch_bwd_rs(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int grid, hipStream_t stream) {
-  const double cus = grid_cu_share(ft_rnn_bwd_rs_kernel<G, NW, NT>, NW * 64, geo.total);
-  if (!admit(cus)) return -1;
-  // only the arrival counters need zeroing: every exchange block is written before it is read
-  (void)hipMemsetAsync(p.cnt, 0, p.cnt_bytes, stream);
+int launch_bwd_rs(const RnnBwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
+  int grid = 0;
+  const double cus = plan_launch(ft_rnn_bwd_rs_kernel<G, NW, NT>, NW * 64, geo, grid, stream);
+  if (cus < 0.0) return -1;
+  // only the sync region (counters, flags, XCC ids) needs zeroing: every exchange block is written before it is read
+  (void)hipMemsetAsync(p.cnt, 0, p.sync_bytes, stream);
   hipLaunchKernelGGL((ft_rnn_bwd_rs_kernel<G, NW, NT>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
                      ft_rnn_fault_word(), (unsigned)p.xb_bytes);
   admitted_launch_done(cus, stream);
@@ -958,7 +1125,7 @@ int launch_bwd_rs(const RnnBwdArgs& a, const Geom& geo, const PersistWs& p, int 
 
 // reduce-scatter form: H/16 output tiles over NW waves, NT tiles each; -1 if it does not apply
 template <int G>
-int bwd_persistent_rs(RnnBwdArgs a, const Geom& geo, void* ws, size_t ws_bytes, int grid, hipStream_t stream) {
+int bwd_persistent_rs(RnnBwdArgs a, const Geom& geo, void* ws, size_t ws_bytes, hipStream_t stream) {
   const int tiles = a.H / 16;
   if (!env_int("FT_RNN_BWD_RS", 1) || !env_int("FT_RNN_B3", 1) || !geo.sig_per_wave) return -1;
   PersistWs p = carve_ws_rs(ws, 2 * geo.nbg, geo.nchunks);
@@ -969,10 +1136,10 @@ int bwd_persistent_rs(RnnBwdArgs a, const Geom& geo, void* ws, size_t ws_bytes, 
   const bool force = env_int("FT_RNN_BWD_RS", 1) == 2;
   if (!force && G * a.H < 1024) return -1;
   switch (tiles) {
-    case 4: return launch_bwd_rs<G, 4, 1>(a, geo, p, grid, stream);
-    case 8: return launch_bwd_rs<G, 8, 1>(a, geo, p, grid, stream);
-    case 16: return launch_bwd_rs<G, 8, 2>(a, geo, p, grid, stream);
-    case 32: return launch_bwd_rs<G, 8, 4>(a, geo, p, grid, stream);
+    case 4: return launch_bwd_rs<G, 4, 1>(a, geo, p, stream);
+    case 8: return launch_bwd_rs<G, 8, 1>(a, geo, p, stream);
+    case 16: return launch_bwd_rs<G, 8, 2>(a, geo, p, stream);
+    case 32: return launch_bwd_rs<G, 8, 4>(a, geo, p, stream);
     default: return -1;
   }
 }
@@ -995,24 +1162,25 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
   geo.sig_per_wave = env_int("FT_RNN_SIG", 1);
   geo.max_spins = g_max_spins;
-  const int grid = persist_grid(geo);
+  geo.xcd_off = 0;
+  geo.local_ok = 0;
   a.s = 0;
   {
-    const int rc = bwd_persistent_rs<G>(a, geo, ws, ws_bytes, grid, stream);
+    const int rc = bwd_persistent_rs<G>(a, geo, ws, ws_bytes, stream);
     if (rc != -1) return rc;
   }
   PersistWs p = carve_ws(ws, 2 * geo.nbg, K);
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   if (K % 32 == 0 && ft_cdiv(K / 32, NW) <= GW / 2 && env_int("FT_RNN_B3", 1)) {
-    if (NW == 16) return launch_bwd_persist<G, 16, 16, true>(a, geo, p, grid, stream);
-    if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, true>(a, geo, p, grid, stream)
-                                 : launch_bwd_persist<G, 8, 8, true>(a, geo, p, grid, stream);
-    return launch_bwd_persist<G, 4, 8, true>(a, geo, p, grid, stream);
+    if (NW == 16) return launch_bwd_persist<G, 16, 16, true>(a, geo, p, stream);
+    if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, true>(a, geo, p, stream)
+                                 : launch_bwd_persist<G, 8, 8, true>(a, geo, p, stream);
+    return launch_bwd_persist<G, 4, 8, true>(a, geo, p, stream);
   }
-  if (NW == 16) return launch_bwd_persist<G, 16, 16, false>(a, geo, p, grid, stream);
-  if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, false>(a, geo, p, grid, stream)
-                               : launch_bwd_persist<G, 8, 8, false>(a, geo, p, grid, stream);
-  return launch_bwd_persist<G, 4, 8, false>(a, geo, p, grid, stream);
+  if (NW == 16) return launch_bwd_persist<G, 16, 16, false>(a, geo, p, stream);
+  if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, false>(a, geo, p, stream)
+                               : launch_bwd_persist<G, 8, 8, false>(a, geo, p, stream);
+  return launch_bwd_persist<G, 4, 8, false>(a, geo, p, stream);
 }
 
 }  // namespace
@@ -1060,9 +1228,30 @@ int ft_rnn_set_max_spins(int max_spins) {
   return old;
 }
 
+int ft_rnn_note_join(void* waiting_stream, void* joined_stream) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lk(g_adm_mu);
+  for (Flight& f : g_flights[dev])
+    if (f.stream == (hipStream_t)joined_stream) f.joined_by.push_back((hipStream_t)waiting_stream);
+  return FT_OK;
+}
+
 int ft_rnn_counters(long* persistent_launches, long* refused_launches) {
   if (persistent_launches) *persistent_launches = g_n_persistent;
   if (refused_launches) *refused_launches = g_n_refused;
+  return FT_OK;
+}
+
+int ft_rnn_mode_counts(long* xcd_local_groups, long* agent_scope_groups) {
+  unsigned* w = ft_rnn_fault_word();
+  unsigned v[2] = {0, 0};
+  if (!w || hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(v, w + 8, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) {
+    ft_set_error("rnn_mode_counts: HIP error while reading the counters");
+    return FT_ERR_HIP;
+  }
+  if (xcd_local_groups) *xcd_local_groups = v[0];
+  if (agent_scope_groups) *agent_scope_groups = v[1];
   return FT_OK;
 }
 

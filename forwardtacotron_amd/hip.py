@@ -726,6 +726,18 @@ def check_rnn_status(clear: bool = True) -> None:
     _lib.call('ft_rnn_status', int(clear))
 
 
+def rnn_note_join(waiting: 'torch.cuda.Stream', joined: 'torch.cuda.Stream') -> None:
+    """call right after waiting.wait_stream(joined): see ft_rnn_note_join (include/fwdtaco_hip.h)"""
+    _lib.call('ft_rnn_note_join', waiting.cuda_stream, joined.cuda_stream)
+
+
+def rnn_mode_counts():
+    """((direction, batch group) groups that ran XCD-local, groups on the agent-scope protocol) since load; syncs"""
+    a, b = ctypes.c_long(0), ctypes.c_long(0)
+    _lib.call('ft_rnn_mode_counts', ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
 def rnn_counters():
     """(launches that ran in the persistent form, launches refused admission -> per-step kernels) since load"""
     a, b = ctypes.c_long(0), ctypes.c_long(0)

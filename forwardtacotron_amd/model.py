@@ -390,6 +390,13 @@ class ForwardTacotron(nn.Module):
             torch.fill_(dur_hat, value=2.)
         pitch_hat = pitch_function(self.pitch_pred(x).transpose(1, 2))
         energy_hat = energy_function(self.energy_pred(x).transpose(1, 2))
+        return self._generate_mel(x, dur_hat, pitch_hat, energy_hat)
+
+    def _generate_mel(self, x: torch.Tensor, dur_hat: torch.Tensor, pitch_hat: torch.Tensor,
+                      energy_hat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """forward_tacotron.py:205-234: mel generation from given durations [B,Tx], pitch and energy [B,1,Tx]; the LSTM
+        runs over the padded length (no packing).  `dur_hat` is clamped in place like every LengthRegulator input."""
+        self._require_device(x)
         dur_in = dur_hat.contiguous()
         mel_cl, post_cl = self._trunk(x, dur_in, pitch_hat.reshape(x.shape[0], -1).contiguous(),
                                       energy_hat.reshape(x.shape[0], -1).contiguous(), None)

@@ -271,7 +271,9 @@ int ft_masked_l1_bwd(const float* x, const float* target, const long* lens, cons
  * steps with W_hh resident in registers and h exchanged between workgroups inside the kernel (bounded spins).
  * It is used when H % 16 == 0, the grid is co-resident per the occupancy query and FT_RNN_PERSISTENT != 0;
  * otherwise one kernel per timestep is launched.  A launch is admitted only while the persistent grids still in flight
- * on the device (any stream) plus its own fit the chip, because every workgroup spins until its whole grid is resident.
+ * on OTHER streams of the device plus its own fit every XCD in the worst case, because every workgroup spins until its
+ * whole grid is resident.  Grids whose (direction, batch group) groups each fit one XCD slot are laid out that way and
+ * hand h / d(gates) over through that XCD's L2 (placement verified in the kernel, agent-scope protocol otherwise).
  * Faults: a workgroup whose bounded poll runs out sets the device's STICKY fault word and leaves (the grid drains);
  * no launch clears that word.  ft_clip_grad_norm / ft_adam_step read it on the device and skip the parameter update;
  * ft_rnn_status(clear) synchronises the device, returns an error if the word is set and (clear != 0) resets it. */
@@ -282,6 +284,14 @@ int ft_rnn_set_persistent(int enabled);
 /* bound of the arrival polls (0 restores the default 2^18; -1 = fault injection for tests: every poll of every
  * later launch fails at once, deterministically); returns the previous bound (0 while injecting) */
 int ft_rnn_set_max_spins(int max_spins);
+/* Tell the admission bookkeeping that `waiting_stream` has just been made to wait for everything enqueued so far on
+ * `joined_stream` (hipStreamWaitEvent / torch's wait_stream): the joined stream's earlier persistent launches then
+ * precede whatever the waiting stream launches next and no longer count against it.  Optional -- without it the
+ * bookkeeping is merely conservative. */
+int ft_rnn_note_join(void* waiting_stream, void* joined_stream);
+/* (direction, batch group) groups of persistent launches that ran the XCD-local hand-off / the agent-scope one since
+ * the library loaded (synchronises the device) */
+int ft_rnn_mode_counts(long* xcd_local_groups, long* agent_scope_groups);
 /* launches that ran in the persistent form / that were refused admission (and ran per-step) since the library loaded */
 int ft_rnn_counters(long* persistent_launches, long* refused_launches);
 int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,

@@ -291,7 +291,9 @@ def pad_to(x: Tensor, max_len: int, pad_value: float = PAD_VALUE) -> Tensor:
     return x
 
 
-def _trunk(x_idx, dur, pitch, energy, mel_lens, P, cfg, training, new_buffers):
+def _trunk(x_idx, dur, pitch, energy, mel_lens, P, cfg, training, new_buffers, pad_frames_to=None):
+    """pad_frames_to: zero-pad the LengthRegulator output to this many frames -- what pad_sequence does to an item that
+    sits in a batch beside a longer one (common_layers.py:23); lets one item of a large batch be checked alone."""
     x = embedding(x_idx, P['embedding.weight']).transpose(1, 2)
     x = cbhg(x, P, 'prenet.', cfg['prenet_k'], cfg['prenet_num_highways'], training, new_buffers)
     pp = conv1d(pitch, P['pitch_proj.weight'], P['pitch_proj.bias']).transpose(1, 2)
@@ -299,6 +301,8 @@ def _trunk(x_idx, dur, pitch, energy, mel_lens, P, cfg, training, new_buffers):
     ep = conv1d(energy, P['energy_proj.weight'], P['energy_proj.bias']).transpose(1, 2)
     x = x + ep * cfg['energy_strength']
     x = length_regulate(x, dur)
+    if pad_frames_to is not None and x.shape[1] < pad_frames_to:
+        x = torch.cat([x, torch.zeros(x.shape[0], pad_frames_to - x.shape[1], x.shape[2], dtype=x.dtype)], dim=1)
     x = bilstm(x, mel_lens, P, 'lstm.', cfg.get('padding_value', PAD_VALUE))
     x = linear(x, P['lin.weight'], P['lin.bias']).transpose(1, 2)
     xp = cbhg(x, P, 'postnet.', cfg['postnet_k'], cfg['postnet_num_highways'], training, new_buffers)
@@ -340,6 +344,15 @@ def generate(P: Dict[str, Tensor], x_idx: Tensor, cfg: dict, alpha: float = 1.0,
         pitch_hat = pitch_function(series_predictor(x_idx, P, 'pitch_pred.', False).transpose(1, 2))
         energy_hat = energy_function(series_predictor(x_idx, P, 'energy_pred.', False).transpose(1, 2))
         x, xp = _trunk(x_idx, dur_hat, pitch_hat, energy_hat, None, P, cfg, False, None)
+        return {'mel': x, 'mel_post': xp, 'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat}
+
+
+def generate_mel(P: Dict[str, Tensor], x_idx: Tensor, dur_hat: Tensor, pitch_hat: Tensor, energy_hat: Tensor,
+                 cfg: dict, pad_frames_to: Optional[int] = None) -> Dict[str, Tensor]:
+    """ForwardTacotron._generate_mel (forward_tacotron.py:205-234): eval-mode mel generation from GIVEN durations
+    [B,Tx], pitch / energy [B,1,Tx].  pad_frames_to: see _trunk."""
+    with torch.no_grad():
+        x, xp = _trunk(x_idx, dur_hat, pitch_hat, energy_hat, None, P, cfg, False, None, pad_frames_to)
         return {'mel': x, 'mel_post': xp, 'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat}
 
 

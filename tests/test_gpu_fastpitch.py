@@ -334,3 +334,39 @@ def test_fastpitch_mid_size_vs_oracle():
         if d > worst:
             worst, wk = d, k
     assert worst < 2e-4, (worst, wk)
+
+
+def test_fastpitch_full_size_properties():
+    """BASELINE configs[2] shape (fp32 arithmetic): singlespeaker.yaml FastPitch, bs=32, Tx=128, Tm=841.  No oracle at
+    this size: the padding value is reproduced exactly beyond mel_len, mel_post is mel (fast_pitch.py:161-162), eval is
+    deterministic, everything is finite, and one TrainStep moves every parameter by at most lr (first Adam step)."""
+    from forwardtacotron_amd import data
+    from forwardtacotron_amd.fastpitch import FastPitch
+    from forwardtacotron_amd.trainer import TrainStep
+    torch.manual_seed(0)
+    cfg = dict(data.FASTPITCH_MODEL)
+    m = FastPitch(**cfg).cuda().eval()
+    batch = data.to_device(data.synthetic_batch(B=32, Tmax=128, n_mels=80, seed=0), 'cuda')
+    Tm = int(batch['mel_len'].max())
+    assert Tm == 841
+    dur0 = batch['dur'].clone()
+    with torch.no_grad():
+        a = m(batch)
+        batch['dur'].copy_(dur0)
+        b = m(batch)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert bool(torch.isfinite(a[k]).all()), k
+    assert tuple(a['mel'].shape) == (32, 80, Tm + 1) and torch.equal(a['mel'], a['mel_post'])
+    assert bool((a['mel'][:, :, Tm:] == -11.5129).all())
+    for p_ in m.modules():                     # dropout at 0 for the |delta| <= lr property (masks rescale by 1/(1-p))
+        if hasattr(p_, 'p'):
+            p_.p = 0.0
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    ts = TrainStep(m, lr=1e-4, train_cfg=dict(data.SINGLESPEAKER_TRAIN))
+    batch['dur'].copy_(dur0)
+    out = ts.step(batch)
+    ts.check()
+    assert bool(torch.isfinite(out['loss'])) and float(out['grad_norm']) > 0
+    worst = max(float((p.detach() - before[n]).abs().max()) for n, p in m.named_parameters())
+    assert 0 < worst <= 1e-4 * 1.01

@@ -318,6 +318,58 @@ def test_long_form_eval_vs_oracle(ft):
         assert maxdiff(got[k].cpu(), want[k]) < 1e-4, k
 
 
+def test_long_form_full_shape(ft):
+    """BASELINE configs[4] at its FULL shape: singlespeaker.yaml model, B=128 items x 1000 token slots (x_len 500..1000),
+    explicit durations ~ randint(1,12) through _generate_mel (forward_tacotron.py:205-234; an untrained duration
+    predictor degenerates to the fill_(2.) fallback) -- ~575 k frames, a [128,~6000,512] LengthRegulator
+    output, a 780 k-row conv bank.  Checks: the LengthRegulator's rows are bit-exact copies of their source tokens
+    (want_src index map vs the numpy oracle map); every output finite; and TWO items -- the longest and a short one,
+    which sits beside ~2500 zero-padded frames -- equal the oracle's _generate_mel run on that item ALONE, zero-padded
+    to the batch's frame count (eval-mode BatchNorm is per-position, so batch items are independent)."""
+    model, ops, hip = ft
+    from forwardtacotron_amd import data
+    from oracle import ft_oracle as O
+    cfg = dict(data.SINGLESPEAKER_MODEL)
+    torch.manual_seed(0)
+    m = model.ForwardTacotron(**cfg).eval()
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    batch = data.synthetic_batch(B=128, Tmax=1000, n_mels=80, seed=0)
+    x, dur = batch['x'], batch['dur']
+    pitch, energy = batch['pitch'].unsqueeze(1), batch['energy'].unsqueeze(1)
+    total = batch['mel_len']
+    Tm = int(total.max())
+    assert int(total.sum()) > 500_000 and Tm > 5500
+    torch.cuda.reset_peak_memory_stats()
+    with torch.no_grad():
+        out = m._generate_mel(x.cuda(), dur.clone().cuda(), pitch.cuda(), energy.cuda())
+    torch.cuda.synchronize()
+    hip.check_rnn_status()
+    assert tuple(out['mel'].shape) == (128, 80, Tm) and tuple(out['mel_post'].shape) == (128, 80, Tm)
+    assert bool(torch.isfinite(out['mel']).all()) and bool(torch.isfinite(out['mel_post']).all())
+    # LengthRegulator index map at the full shape, bit-exact rows
+    src_want, tot_want = O.lr_index_map(dur.numpy())
+    cum, tot = hip.lr_scan(dur.clone().cuda())
+    assert np.array_equal(tot.cpu().numpy(), tot_want)
+    rows = torch.randn(128, 1000, 64, device='cuda')
+    y, src = hip.lr_expand(rows, cum, Tm, want_src=True)
+    assert np.array_equal(src.cpu().numpy(), src_want)
+    bi = torch.arange(128, device='cuda').unsqueeze(1).expand(128, Tm)
+    valid = src >= 0
+    assert torch.equal(y[valid], rows[bi[valid], src[valid].long()]) and float(y[~valid].abs().sum()) == 0.0
+    del rows, y
+    # two items against the oracle run on each alone (padded to the batch's frame count)
+    for b in (int(total.argmax()), int(total.argmin()), 17):
+        want = O.generate_mel(P, x[b:b + 1], dur[b:b + 1].clone(), pitch[b:b + 1], energy[b:b + 1], cfg,
+                              pad_frames_to=Tm)
+        n = int(total[b])
+        for k in ('mel', 'mel_post'):
+            assert want[k].shape[-1] == Tm
+            assert maxdiff(out[k][b, :, :n].cpu(), want[k][0, :, :n]) < 1e-4, (k, b)
+            assert maxdiff(out[k][b].cpu(), want[k][0]) < 1e-4, (k, b, 'padded frames')
+    assert torch.cuda.max_memory_allocated() < 80 * 2 ** 30
+
+
 def test_full_size_properties(ft):
     """The benchmark configuration itself (singlespeaker.yaml, bs=32, Tx=128, Tm=841): no oracle at this size, so the
     size-independent properties -- padding value beyond mel_len is reproduced exactly, LengthRegulator output rows are

@@ -81,3 +81,104 @@ def test_multispeaker_train_step_through_trainer():
     for k, v in sub(M, 'sd_after/').items():
         if v.dtype.is_floating_point:
             assert maxdiff(sd[k].cpu(), v) < 3e-5, k
+
+
+MID_MULTI = dict(embed_dims=128, series_embed_dims=32, num_chars=135,
+                 durpred_conv_dims=64, durpred_rnn_dims=32, durpred_dropout=0.0,
+                 pitch_conv_dims=64, pitch_rnn_dims=32, pitch_dropout=0.0, pitch_strength=1.0,
+                 pitch_cond_conv_dims=64, pitch_cond_rnn_dims=32, pitch_cond_dropout=0.0,
+                 energy_conv_dims=64, energy_rnn_dims=32, energy_dropout=0.0, energy_strength=1.0,
+                 rnn_dims=256, prenet_dims=256, prenet_k=4, postnet_num_highways=2,
+                 prenet_dropout=0.0, postnet_dims=128, postnet_k=4, prenet_num_highways=2,
+                 postnet_dropout=0.0, n_mels=80, speaker_emb_dims=256, pitch_cond_emb_dims=4,
+                 pitch_cond_categorical_dims=3)
+
+
+def _multi_batch(B, Tmax, seed):
+    from oracle import ft_oracle as O
+    batch = O.synthetic_batch(B=B, Tmax=Tmax, n_mels=80, seed=seed)
+    batch['pitch_cond'] = ((batch['pitch'] != 0).long() + 1) * (batch['x'] > 0).long()
+    se = torch.randn(B, 256, generator=torch.Generator().manual_seed(seed + 100))
+    batch['speaker_emb'] = se / se.norm(dim=1, keepdim=True)
+    return batch
+
+
+def test_multispeaker_mid_size_train_step_vs_oracle():
+    """one optimisation step of MultiForwardTacotron through TrainStep at sizes where the wide paths run
+    -- 128x128 bf16-split GEMM tiles (forward, data and weight gradients), the 768-wide LSTM input of the shipped
+    multispeaker model (2 x 256 prenet + 256 speaker), persistent recurrences incl. the reduce-scatter backward
+    (G*H = 1024), one-launch bank weight gradients -- against oracle.multi_train_step: losses incl. the CrossEntropy
+    term, gradient norm, every parameter after Adam, BN statistics (multi_forward_tacotron.py:186-241)."""
+    from forwardtacotron_amd import hip as H
+    from forwardtacotron_amd.multi_model import MultiForwardTacotron
+    from forwardtacotron_amd.trainer import TrainStep
+    from oracle import ft_oracle as O
+    torch.manual_seed(31)
+    m = MultiForwardTacotron(**MID_MULTI)
+    assert m.lstm.weight_ih_l0.shape == (4 * 256, 768)
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    batch = _multi_batch(B=8, Tmax=96, seed=6)
+    assert int(batch['mel_len'].max()) * 8 > 4000
+    lr = 1e-3
+    newP, _, info = O.multi_train_step(P, {}, {k: v.clone() for k, v in batch.items()}, MID_MULTI, TRAIN_CFG_MULTI, lr, 1)
+    m = m.cuda()
+    ts = TrainStep(m, lr=lr, train_cfg=TRAIN_CFG_MULTI)
+    n0 = H.rnn_counters()[0]
+    out = ts.step({k: v.clone().cuda() for k, v in batch.items()})
+    ts.check()
+    H.check_rnn_status()
+    assert H.rnn_counters()[0] > n0                       # persistent recurrences really ran
+    for k in ('loss', 'mel', 'mel_post', 'dur', 'pitch', 'energy', 'pitch_cond'):
+        assert abs(float(out[k]) - float(info['losses'][k])) < 5e-5, k
+    gn = float(info['grad_norm'])
+    assert abs(float(out['grad_norm']) - gn) < 2e-4 * max(1.0, gn)
+    sd = m.state_dict()
+    worst, worst_k = 0.0, None
+    for k, v in newP.items():
+        if not v.dtype.is_floating_point:
+            continue
+        if 'running_' in k:
+            assert maxdiff(sd[k].cpu(), v) < 1e-5 * max(1.0, float(v.abs().max())), k
+        elif k in info['grads']:
+            big = info['grads'][k].abs() > 1e-6            # Adam moves rounding-noise gradients by +-lr
+            if bool(big.any()):
+                d = float((sd[k].cpu() - v).abs()[big].max())
+                if d > worst:
+                    worst, worst_k = d, k
+    assert worst < 1e-4, (worst, worst_k)
+
+
+def test_multispeaker_full_size_properties():
+    """BASELINE configs[3] per GPU: multispeaker.yaml model, bs=64 (Tm = 811, 37,819 frames).  No oracle at this size:
+    padding value reproduced exactly beyond mel_len, eval deterministic, every output finite, and one TrainStep moves
+    every parameter by at most lr (first Adam step) with a clean recurrence status."""
+    from forwardtacotron_amd import data, hip as H
+    from forwardtacotron_amd.multi_model import MultiForwardTacotron
+    from forwardtacotron_amd.trainer import TrainStep
+    torch.manual_seed(0)
+    m = MultiForwardTacotron(**data.MULTISPEAKER_MODEL).cuda().eval()
+    batch = {k: v.cuda() for k, v in _multi_batch(B=64, Tmax=128, seed=0).items()}
+    Tm = int(batch['mel_len'].max())
+    assert Tm == 811 and int(batch['mel_len'].sum()) == 37819           # SURVEY 8d
+    dur0 = batch['dur'].clone()
+    with torch.no_grad():
+        a = m(batch)
+        batch['dur'].copy_(dur0)
+        b = m(batch)
+    H.check_rnn_status()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert bool(torch.isfinite(a[k]).all()), k
+    assert tuple(a['mel'].shape) == (64, 80, Tm + 1) and tuple(a['pitch_cond'].shape) == (64, 128, 3)
+    pad = torch.arange(Tm + 1, device='cuda').unsqueeze(0) >= batch['mel_len'].unsqueeze(1)
+    for k in ('mel', 'mel_post'):
+        assert bool((a[k].transpose(1, 2)[pad] == -11.5129).all()), k
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    ts = TrainStep(m, lr=1e-4, train_cfg=dict(data.SINGLESPEAKER_TRAIN, pitch_cond_loss_factor=0.1))
+    batch['dur'].copy_(dur0)
+    out = ts.step(batch)
+    ts.check()
+    H.check_rnn_status()
+    assert bool(torch.isfinite(out['loss'])) and float(out['grad_norm']) > 0 and float(out['rnn_fault']) == 0.0
+    worst = max(float((p.detach() - before[n]).abs().max()) for n, p in m.named_parameters())
+    assert 0 < worst <= 1e-4 * 1.01
