@@ -134,20 +134,15 @@ __device__ __forceinline__ unsigned xcc_id() {
   return v & 0xFu;
 }
 
-// XCD-local mode: wave 0 waits until the n flag words of the group (n % 4 == 0, n <= NFLAG) all hold >= step; the
-// loads bypass L1 (sc1) and are served by the XCD's L2, where the producers' plain flag stores land
-__device__ __forceinline__ bool wait_flags(const unsigned* f, unsigned step, int n, int lane, unsigned max_spins) {
+// XCD-local mode: EVERY wave polls, on its own, the flag words of the producers of its own operand slice (lane l polls
+// the word f, or nothing if f is null) until each holds >= step.  The loads bypass L1 (sc1) and are served by the XCD's
+// L2, where the producers' plain flag stores land; no sleep: an L2 poll costs the fabric nothing.
+__device__ __forceinline__ bool poll_flag(const unsigned* f, unsigned step, unsigned max_spins) {
   bool ok = max_spins != 0;              // 0 = fault injection
-  if (4 * lane < n) {
+  if (f) {
     unsigned spins = 0;
-    while (ok) {
-      const unsigned a = __hip_atomic_load(f + 4 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned b = __hip_atomic_load(f + 4 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned c = __hip_atomic_load(f + 4 * lane + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned d = __hip_atomic_load(f + 4 * lane + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (min(min(a, b), min(c, d)) >= step) break;
+    while (ok && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < step)
       if (++spins > max_spins) ok = false;
-    }
   }
   return __all(ok);
 }
@@ -180,7 +175,9 @@ template <int G, int NW, bool B3>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                      unsigned* fault, unsigned xb_bytes) {
   constexpr int UB = 8, NT = 2, BCH = GCH / 2;
-  __shared__ float red[NW * NT * 16 * RLD];
+  // partial tiles, double-buffered by step parity: in XCD-local mode no barrier separates a step's readers (cell
+  // threads) from the next step's writers
+  __shared__ float red2[2 * NW * NT * 16 * RLD];
   __shared__ int s_ok;
   int d, bgp, chunk, grp;
   if (!decode(geo, d, bgp, chunk, grp)) return;
@@ -200,10 +197,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
   unsigned* myflags = cnt + (long)2 * geo.nbg * NSH * CSTRIDE + (long)grp * NFLAG;
   unsigned* myxcc = cnt + (long)2 * geo.nbg * (NSH * CSTRIDE + NFLAG) + (long)grp * NXCC;
   const unsigned my_xcc = xcc_id() + 1u;
-  __shared__ int s_local;
+  __shared__ int s_local, s_fail;
   bool local = false;
   if (tid == 0) {
     s_local = 0;
+    s_fail = 0;
     __hip_atomic_store(myxcc + chunk, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // drained before wave 0's first signal
   }
 
@@ -239,6 +237,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     }
   }
 
+  // XCD-local mode: this wave's operand slice is k-quads [q0, q0 + nq4) of h; the signalling wave (2*chunk' + jq') that
+  // produced quad i has flag index i
+  const int pq0 = B3 ? 8 * kb0 : 4 * g0, pnq = B3 ? 8 * max(kb1 - kb0, 0) : 4 * max(g1 - g0, 0);
+  const unsigned* pollf = lane < pnq ? myflags + pq0 + lane : nullptr;
+
   // ---- cell threads (waves 0 and 1): wave jq owns units 4*jq..4*jq+3 of the chunk = one [16][4] exchange block
   const int jq = tid >> 6, ci = (tid >> 2) & 15, jj = tid & 3;
   const int cu = 4 * jq + jj;
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
   for (int s = 0; s < T; ++s) {
     const bool cact = cthr && s < L;
     const int ct = d == 0 ? s : L - 1 - s;
+    float* red = red2 + (s & 1) * (NW * NT * 16 * RLD);
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -271,23 +275,26 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     float4 av[B3 ? 1 : GCH];
     float4 aw[B3 ? BCH : 1][2];
     if (s > 0) {
-      if (wave == 0) {
-        const bool ok = local ? wait_flags(myflags, (unsigned)s, nprod, lane, geo.max_spins)
-                              : wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
-        if (s == 1 && ok && geo.local_ok) {
-          const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
-          if (lane == 0) s_local = same;
+      if (local) {       // every wave waits for the producers of its own slice; a timeout is acted on at the next barrier
+        if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
+      } else {
+        if (wave == 0) {
+          const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+          if (s == 1 && ok && geo.local_ok) {
+            const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
+            if (lane == 0) s_local = same;
+          }
+          if (lane == 0) s_ok = ok;
         }
-        if (lane == 0) s_ok = ok;
-      }
-      __syncthreads();
-      if (!s_ok) {
-        if (tid == 0) atomicExch(fault, 1u);
-        return;
-      }
-      if (s == 1) {
-        local = s_local != 0;
-        if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);      // statistics: groups per mode
+        __syncthreads();
+        if (!s_ok) {
+          if (tid == 0) atomicExch(fault, 1u);
+          return;
+        }
+        if (s == 1) {
+          local = s_local != 0;
+          if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);    // statistics: groups per mode
+        }
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
       if constexpr (!B3) {
@@ -338,6 +345,10 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     }
     store_partials<NT>(red, wave, lane, acc);
     __syncthreads();
+    if (s_fail) {                                          // a wave's poll ran out (XCD-local mode): leave together
+      if (tid == 0) atomicExch(fault, 1u);
+      return;
+    }
 
     float hnew = 0.f, cnew = 0.f, sg[4] = {0.f, 0.f, 0.f, 0.f};
     if (cact) {
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
 template <int G, int NW, int GW, bool B3>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                      unsigned* fault, unsigned xb_bytes) {
-  __shared__ float red[NW * 16 * RLD];
+  __shared__ float red2[2 * NW * 16 * RLD];            // double-buffered by step parity (see the forward kernel)
   __shared__ int s_ok;
   int d, bgp, chunk, grp;
   if (!decode(geo, d, bgp, chunk, grp)) return;
@@ -432,10 +443,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
   unsigned* myflags = cnt + (long)2 * geo.nbg * NSH * CSTRIDE + (long)grp * NFLAG;      // XCD-local mode (file header)
   unsigned* myxcc = cnt + (long)2 * geo.nbg * (NSH * CSTRIDE + NFLAG) + (long)grp * NXCC;
   const unsigned my_xcc = xcc_id() + 1u;
-  __shared__ int s_local;
+  __shared__ int s_local, s_fail;
   bool local = false;
   if (threadIdx.x == 0) {
     s_local = 0;
+    s_fail = 0;
     __hip_atomic_store(myxcc + chunk, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
@@ -464,6 +476,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
              bw[c][1], bw[c][2]);
     }
   }
+
+  // XCD-local mode: this wave's operand slice is k-quads [q0, q0 + nq4) of d(gates), k = gate*H + unit; the signalling
+  // wave (4*chunk' + j4') that produced a quad has flag index unit / 4 (it writes its 4 units for every gate)
+  const int pq0 = B3 ? 8 * kb0 : 4 * g0, pnq = B3 ? 8 * max(kb1 - kb0, 0) : 4 * max(g1 - g0, 0);
+  const unsigned* pollf = lane < pnq ? myflags + ((4 * (pq0 + lane)) % H) / 4 : nullptr;
 
   // ---- cell threads (first 256): wave j4 owns units 4*j4..4*j4+3 -> whole [16][4] exchange blocks, one per gate
   const int j4 = tid >> 6, ci = (tid >> 2) & 15, jj = tid & 3;
@@ -503,29 +520,33 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
   for (int s = 0; s < T; ++s) {
     const bool cact = cthr && s < L;
     const int ct = d == 0 ? L - 1 - s : s;
+    float* red = red2 + (s & 1) * (NW * 16 * RLD);
     f32x4 acc[1];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[0][e] = 0.f;
     float4 av[B3 ? 1 : GW];
     float4 aw[B3 ? BW : 1][2];
     if (s > 0) {
-      if (wave == 0) {
-        const bool ok = local ? wait_flags(myflags, (unsigned)s, nprod, lane, geo.max_spins)
-                              : wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
-        if (s == 1 && ok && geo.local_ok) {
-          const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
-          if (lane == 0) s_local = same;
+      if (local) {       // every wave waits for the producers of its own slice; a timeout is acted on at the next barrier
+        if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
+      } else {
+        if (wave == 0) {
+          const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+          if (s == 1 && ok && geo.local_ok) {
+            const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
+            if (lane == 0) s_local = same;
+          }
+          if (lane == 0) s_ok = ok;
         }
-        if (lane == 0) s_ok = ok;
-      }
-      __syncthreads();
-      if (!s_ok) {
-        if (tid == 0) atomicExch(fault, 1u);
-        return;
-      }
-      if (s == 1) {
-        local = s_local != 0;
-        if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);      // statistics: groups per mode
+        __syncthreads();
+        if (!s_ok) {
+          if (tid == 0) atomicExch(fault, 1u);
+          return;
+        }
+        if (s == 1) {
+          local = s_local != 0;
+          if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);    // statistics: groups per mode
+        }
       }
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
       if constexpr (!B3) {
@@ -564,6 +585,10 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
     }
     store_partials<1>(red, wave, lane, acc);
     __syncthreads();
+    if (s_fail) {                                          // a wave's poll ran out (XCD-local mode): leave together
+      if (tid == 0) atomicExch(fault, 1u);
+      return;
+    }
 
     float dgx[4] = {0.f, 0.f, 0.f, 0.f}, dgh2 = 0.f;
     if (cact) {
@@ -664,7 +689,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
                                                                 unsigned* fault, unsigned xb_bytes) {
   constexpr int ALD = 68;                             // LDS row stride of the local d(gates) tile [16][64]
   constexpr int PC = NW * NT;                         // chunks per group = H / 16 (checked by the host)
-  __shared__ __attribute__((aligned(16))) float adg[16 * ALD];
+  __shared__ __attribute__((aligned(16))) float adg2[2 * 16 * ALD];   // double-buffered by step parity
   __shared__ int s_ok;
   int d, bgp, chunk, grp;
   if (!decode(geo, d, bgp, chunk, grp)) return;
@@ -683,10 +708,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
   unsigned* myflags = cnt + (long)2 * geo.nbg * NSH * CSTRIDE + (long)grp * NFLAG;      // XCD-local mode (file header)
   unsigned* myxcc = cnt + (long)2 * geo.nbg * (NSH * CSTRIDE + NFLAG) + (long)grp * NXCC;
   const unsigned my_xcc = xcc_id() + 1u;
-  __shared__ int s_local;
+  __shared__ int s_local, s_fail;
   bool local = false;
   if (threadIdx.x == 0) {
     s_local = 0;
+    s_fail = 0;
     __hip_atomic_store(myxcc + chunk, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
@@ -706,7 +732,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
              bw[nt][blk][0], bw[nt][blk][1], bw[nt][blk][2]);
     }
   }
-  for (int i = tid; i < 16 * ALD; i += NW * 64) adg[i] = 0.f;      // (GRU: k 48..63 stay zero)
+  for (int i = tid; i < 2 * 16 * ALD; i += NW * 64) adg2[i] = 0.f;  // (GRU: k 48..63 stay zero)
+
+  // XCD-local mode: a cell wave needs the tile every producer chunk p computed for this consumer chunk; that tile came
+  // from producer wave chunk / NT -> flag NW*p + chunk/NT
+  const unsigned* pollf = (tid < 256 && lane < P) ? myflags + NW * lane + chunk / NT : nullptr;
 
   // ---- cell threads (first 256): thread = (unit cj, row ci), the order of an exchange block
   const int cj = tid >> 4, ci = tid & 15;
@@ -745,25 +775,29 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
   for (int s = 0; s < T; ++s) {
     const bool cact = cthr && s < L;
     const int ct = d == 0 ? L - 1 - s : s;
+    float* adg = adg2 + (s & 1) * (16 * ALD);
     float rec = 0.f;
     if (s > 0) {
-      if (wave == 0) {
-        const bool ok = local ? wait_flags(myflags, (unsigned)s, nprod, lane, geo.max_spins)
-                              : wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
-        if (s == 1 && ok && geo.local_ok) {
-          const bool same = same_xcd(myxcc, P, my_xcc, lane);
-          if (lane == 0) s_local = same;
+      if (local) {       // every wave waits for the producers of its own slice; a timeout is acted on at the next barrier
+        if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
+      } else {
+        if (wave == 0) {
+          const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+          if (s == 1 && ok && geo.local_ok) {
+            const bool same = same_xcd(myxcc, P, my_xcc, lane);
+            if (lane == 0) s_local = same;
+          }
+          if (lane == 0) s_ok = ok;
         }
-        if (lane == 0) s_ok = ok;
-      }
-      __syncthreads();
-      if (!s_ok) {
-        if (tid == 0) atomicExch(fault, 1u);
-        return;
-      }
-      if (s == 1) {
-        local = s_local != 0;
-        if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);      // statistics: groups per mode
+        __syncthreads();
+        if (!s_ok) {
+          if (tid == 0) atomicExch(fault, 1u);
+          return;
+        }
+        if (s == 1) {
+          local = s_local != 0;
+          if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);    // statistics: groups per mode
+        }
       }
       if (sthr) {       // the P partials of (row ci, unit cj), summed in producer order
         const long rbase = (long)((s - 1) & 1) * par_floats + base_floats + (long)chunk * P * 256 + tid;
@@ -808,6 +842,10 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
       for (int g = 0; g < G; ++g) adg[ci * ALD + g * 16 + cj] = (G == 3 && g == 2) ? dgh2 : dgx[g];
     }
     __syncthreads();
+    if (s_fail) {                                          // a wave's poll ran out (XCD-local mode): leave together
+      if (tid == 0) atomicExch(fault, 1u);
+      return;
+    }
 
     if (s + 1 < T) {    // (the last step's product has no reader)
       bf16x8 a3[2][3];
