@@ -38,6 +38,7 @@
 //     a same-step request would sit in front of the exchange loads with its HBM latency);
 //   * 1-D grid with an XCD-aware decode: the 8 XCDs take contiguous ranges of (group, chunk), so a group's exchange
 //     lines and the 128-B lines of out / gates / xp rows are shared inside one or two L2s instead of all eight.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -1087,7 +1088,11 @@ double plan_launch(KernelT kernel, int block, Geom& geo, int& grid, hipStream_t 
   for (int i = 0; i < 2; ++i) {
     if (cand[i].grid == 0) continue;
     const double d = xcd_demand(kernel, block, cand[i].per);
-    if (d > 1.0 || !admit(d, stream)) continue;
+    const bool ok = d <= 1.0 && admit(d, stream);
+    if (env_int("FT_RNN_DEBUG", 0))
+      fprintf(stderr, "[ft_rnn] block %d total %d nchunks %d: %s layout, %d workgroups per XCD slot, demand %.3f -> %s\n", block,
+              geo.total, geo.nchunks, cand[i].aligned ? "aligned" : "spread", cand[i].per, d, ok ? "admitted" : "refused");
+    if (!ok) continue;
     grid = cand[i].grid;
     geo.xcd_off = cand[i].xcd_off;
     geo.local_ok = cand[i].aligned && env_int("FT_RNN_LOCAL", 1);

@@ -197,6 +197,7 @@ class MultiForwardTacotron(nn.Module):
         x_post = ops.TransposePadFn.apply(post_cl, Tout, self.padding_value)
         x_mel = ops.TransposePadFn.apply(mel_cl, Tout, self.padding_value)
         main.wait_stream(side)
+        H.rnn_note_join(main, side)
         for t in (pitch_cond_hat, dur_hat, pitch_hat, energy_hat):
             t.record_stream(main)
         return {'mel': x_mel, 'mel_post': x_post, 'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat,
@@ -231,6 +232,7 @@ class MultiForwardTacotron(nn.Module):
             self._streams = {}
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
+            ops.register_peer_stream(self._streams[key])      # persistent recurrences run on it beside the trunk's
         return self._streams[key]
 
     def get_step(self) -> int:
