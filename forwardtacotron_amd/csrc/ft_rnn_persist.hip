@@ -170,12 +170,17 @@ __device__ __forceinline__ bool decode(const Geom& g, int& d, int& bgp, int& chu
 }
 
 // ---------------------------------------------------------------------------------------------------
-// forward: workgroup = 16 batch rows x 8 hidden units (all G gates = 2 column tiles), K = H over NW waves
+// forward: workgroup = 16 batch rows x UB hidden units (all G gates = G*UB/16 column tiles), K = H over NW waves.
+// UB = 8 (the UB = 16 instantiation for the 512-wide LSTM -- 32 workgroups per group, one XCD -- exists but loses to
+// register spills, see fwd_persistent)
 // ---------------------------------------------------------------------------------------------------
-template <int G, int NW, bool B3>
+template <int G, int NW, bool B3, int UB>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                      unsigned* fault, unsigned xb_bytes) {
-  constexpr int UB = 8, NT = 2, BCH = GCH / 2;
+  // UB hidden units (all G gates) per workgroup: G*UB columns = NT tiles of 16; cell waves = UB / 4 (one [16][4]
+  // exchange block each)
+  constexpr int NT = (G * UB + 15) / 16, BCH = GCH / 2, CW = UB / 4;
+  static_assert(UB % 4 == 0 && CW <= NW, "cell waves");
   // partial tiles, double-buffered by step parity: in XCD-local mode no barrier separates a step's readers (cell
   // threads) from the next step's writers
   __shared__ float red2[2 * NW * NT * 16 * RLD];
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
   const long par_floats = (long)2 * geo.nbg * grp_floats;                 // one parity
   const long base_floats = (long)grp * grp_floats;
   unsigned* mycnt = cnt + (long)grp * NSH * CSTRIDE;
-  const int nprod = (geo.sig_per_wave ? 2 : 1) * geo.nchunks;             // signalling waves per group
+  const int nprod = (geo.sig_per_wave ? CW : 1) * geo.nchunks;            // signalling waves per group
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xb, 0, (int)xb_bytes, 0x00020000);
   // XCD-local mode state (file header): flag words and published XCC ids of this group
   unsigned* myflags = cnt + (long)2 * geo.nbg * NSH * CSTRIDE + (long)grp * NFLAG;
@@ -238,16 +243,16 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     }
   }
 
-  // XCD-local mode: this wave's operand slice is k-quads [q0, q0 + nq4) of h; the signalling wave (2*chunk' + jq') that
+  // XCD-local mode: this wave's operand slice is k-quads [q0, q0 + nq4) of h; the signalling wave (CW*chunk' + jq') that
   // produced quad i has flag index i
   const int pq0 = B3 ? 8 * kb0 : 4 * g0, pnq = B3 ? 8 * max(kb1 - kb0, 0) : 4 * max(g1 - g0, 0);
   const unsigned* pollf = lane < pnq ? myflags + pq0 + lane : nullptr;
 
-  // ---- cell threads (waves 0 and 1): wave jq owns units 4*jq..4*jq+3 of the chunk = one [16][4] exchange block
+  // ---- cell threads (waves 0 .. CW-1): wave jq owns units 4*jq..4*jq+3 of the chunk = one [16][4] exchange block
   const int jq = tid >> 6, ci = (tid >> 2) & 15, jj = tid & 3;
   const int cu = 4 * jq + jj;
   const int cb = b0 + ci, cun = u0 + cu;
-  const bool sthr = tid < 128;
+  const bool sthr = tid < 64 * CW;
   const bool cthr = sthr && cb < a.B;
   const int L = cthr ? clamp_len(a.lens, cb, T) : 0;
   float bg[G];
@@ -379,19 +384,19 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
         sg[0] = ig; sg[1] = fg; sg[2] = gg; sg[3] = og;
       }
       hprev = hnew;
-      // exchange block [2*chunk + jq][16][4] of parity s&1 (write-through), before anything else
-      float* xw = xb + (long)(s & 1) * par_floats + base_floats + (((long)2 * chunk + jq) * MB + ci) * 4 + jj;
+      // exchange block [CW*chunk + jq][16][4] of parity s&1, before anything else
+      float* xw = xb + (long)(s & 1) * par_floats + base_floats + (((long)CW * chunk + jq) * MB + ci) * 4 + jj;
       if (local) __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain: stays in the XCD's L2
       else __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // write-through (sc1)
     }
     if (geo.sig_per_wave) {
-      if (sthr) {                                          // waves 0 and 1, wave-uniform
+      if (sthr) {                                          // the cell waves, wave-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
           if (local)
-            __hip_atomic_store(myflags + 2 * chunk + jq, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_store(myflags + CW * chunk + jq, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           else
-            __hip_atomic_fetch_add(mycnt + ((2 * chunk + jq) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(mycnt + ((CW * chunk + jq) % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
         }
       }
@@ -1102,14 +1107,14 @@ double plan_launch(KernelT kernel, int block, Geom& geo, int& grid, hipStream_t 
   return -1.0;
 }
 
-template <int G, int NW, bool B3>
+template <int G, int NW, bool B3, int UB>
 int launch_fwd_persist(const RnnFwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
   int grid = 0;
-  const double cus = plan_launch(ft_rnn_fwd_persist_kernel<G, NW, B3>, NW * 64, geo, grid, stream);
+  const double cus = plan_launch(ft_rnn_fwd_persist_kernel<G, NW, B3, UB>, NW * 64, geo, grid, stream);
   if (cus < 0.0) return -1;
   (void)hipMemsetAsync(p.cnt, 0, p.total_bytes, stream);
-  hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb, p.cnt,
-                     ft_rnn_fault_word(), (unsigned)p.xb_bytes);
+  hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3, UB>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb,
+                     p.cnt, ft_rnn_fault_word(), (unsigned)p.xb_bytes);
   admitted_launch_done(cus, stream);
   return ft_check_launch("rnn_fwd_persistent");
 }
@@ -1122,8 +1127,14 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   const int ngroups = H / 16;
   const int NW = ngroups > 16 ? 8 : 4;
   if (ft_cdiv(ngroups, NW) > GCH) return -1;
+  const bool b3 = H % 32 == 0 && ft_cdiv(H / 32, NW) <= GCH / 2 && env_int("FT_RNN_B3", 1);   // bf16 pipe (exact split)
+  // 16 units per workgroup where 8 would need more than the 32 workgroups per group one XCD can host (H = 512): the
+  // group then fits one XCD and runs XCD-local -- but the kernel needs 256 registers per lane AND spills 57 dwords,
+  // measured 5.65 us/step against 3.77 for the 8-unit form on the agent-scope protocol (lab/rnn_step_us.py): off by
+  // default (FT_RNN_FWD_UB16=1 enables it), kept for the day the register diet succeeds
+  const bool wide = b3 && NW == 8 && G == 4 && H / 8 > 32 && H % 16 == 0 && env_int("FT_RNN_FWD_UB16", 0);
   Geom geo;
-  geo.nchunks = H / 8;
+  geo.nchunks = H / (wide ? 16 : 8);
   geo.nbg = ft_cdiv(B, MB);
   geo.total = 2 * geo.nbg * geo.nchunks;
   geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
@@ -1134,11 +1145,12 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.xcd_off = 0;
   geo.local_ok = 0;
   a.s = 0;
-  if (H % 32 == 0 && ft_cdiv(H / 32, NW) <= GCH / 2 && env_int("FT_RNN_B3", 1))     // matmul on the bf16 pipe (exact split)
-    return NW == 8 ? launch_fwd_persist<G, 8, true>(a, geo, p, stream)
-                   : launch_fwd_persist<G, 4, true>(a, geo, p, stream);
-  return NW == 8 ? launch_fwd_persist<G, 8, false>(a, geo, p, stream)
-                 : launch_fwd_persist<G, 4, false>(a, geo, p, stream);
+  if (wide) return launch_fwd_persist<G, 8, true, 16>(a, geo, p, stream);
+  if (b3)
+    return NW == 8 ? launch_fwd_persist<G, 8, true, 8>(a, geo, p, stream)
+                   : launch_fwd_persist<G, 4, true, 8>(a, geo, p, stream);
+  return NW == 8 ? launch_fwd_persist<G, 8, false, 8>(a, geo, p, stream)
+                 : launch_fwd_persist<G, 4, false, 8>(a, geo, p, stream);
 }
 
 template <int G, int NW, int GW, bool B3>

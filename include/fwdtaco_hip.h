@@ -333,6 +333,22 @@ int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scal
 int ft_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                  float beta2, float eps, long step, const float* coef, void* stream);
 
+/* ---- mel inversion + Griffin-Lim (utils/dsp.py:80-94 DSP.griffinlim ; gen_forward.py:109-116) ------------ */
+/* The DFTs are GEMMs on ft_linear_fwd (frames read in place out of the zero-padded signal with ldx = hop); these are
+ * the element-wise / gather pieces.  Complex spectra are split [N][2*Fp] = Re | Im, Fp = F rounded up to 4.
+ * exp_transpose: log-mel [C,T] -> exp -> [T,C].  nnls_step: x = max(0, x - inv_l*g).  sub: out = a - b.
+ * gl_init: proj = S * exp(2 pi i u) (u in [0,1), drawn by the host).  gl_phase: c = rebuilt - alpha*tprev (if has_prev);
+ * proj = S * c / (|c| + FLT_MIN); tprev = rebuilt.  overlap_add: ypad [n_fft + hop*(N-1)] = sum of the (already windowed)
+ * frames [N,n_fft] at offsets n*hop, times inv_wss (1 / summed squared window, 0 where that is below FLT_MIN), zero in
+ * the n_fft/2 margins -- the signal sits at ypad + n_fft/2 and the padded buffer is the next STFT's operand. */
+int ft_exp_transpose(const float* mel_log, float* out, int C, int T, void* stream);
+int ft_nnls_step(float* x, const float* g, float inv_l, long n, void* stream);
+int ft_sub(const float* a, const float* b, float* out, long n, void* stream);
+int ft_gl_init(const float* u, const float* S, float* proj, int N, int Fp, void* stream);
+int ft_gl_phase(const float* rebuilt, float* tprev, const float* S, float* proj, int N, int Fp, float alpha,
+                int has_prev, void* stream);
+int ft_overlap_add(const float* frames, const float* inv_wss, float* ypad, int N, int n_fft, int hop, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,10 @@ def t(f, n=3):
         s.record(); r = f(); e.record(); torch.cuda.synchronize()
         best = min(best, s.elapsed_time(e) * 1e3)
     return best, r
-for G, T, Hh, B in [(4, 841, 512, 32), (3, 841, 128, 32), (3, 128, 256, 32), (3, 128, 64, 32), (3, 128, 128, 32)]:
+shapes = [(4, 841, 512, 32), (3, 841, 128, 32), (3, 128, 256, 32), (3, 128, 64, 32), (3, 128, 128, 32)]
+if len(sys.argv) > 1:
+    shapes = shapes[:int(sys.argv[1])]
+for G, T, Hh, B in shapes:
     xp = torch.randn(T, B, 2 * G * Hh, device=dev) * 0.1
     whh = [torch.randn(G * Hh, Hh, device=dev) * 0.03 for _ in range(2)]
     bhh = [torch.zeros(G * Hh, device=dev) for _ in range(2)]
