@@ -113,6 +113,8 @@ int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStr
 int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
                          hipStream_t stream);
 bool ft_gemm_b3_enabled();
+// 0 = fp32-exact (default), 1 = bf16 operands / fp32 accumulate on every NT-form fast launch (ft_set_gemm_precision)
+int ft_gemm_precision();
 int ft_launch_gemm_tn(const FtGemmTNTask& task, float* workspace, size_t workspace_floats,
                       hipStream_t stream);
 size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& task);

@@ -613,6 +613,14 @@ bool ft_gemm_b3_enabled() {
   return v == 1;
 }
 
+static int g_gemm_precision = 0;
+int ft_gemm_precision() { return g_gemm_precision; }
+extern "C" int ft_set_gemm_precision(int bf16) {
+  const int old = g_gemm_precision;
+  g_gemm_precision = bf16 ? 1 : 0;
+  return old;
+}
+
 size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& t) {
   // the query does not know the operands' alignment yet: cover both plans the launcher may pick
   const TNPlan p0 = plan_tn(t, false), p1 = plan_tn(t, true);
@@ -673,7 +681,8 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   GemmLog log;
   log.begin(stream);
   // the 64x64 tile gains nothing from the split path (its staging per MFMA is twice the 128-tile's): f32 kernel there
-  const bool b3 = fast && !b_ncontig && big && ft_gemm_b3_enabled();
+  // bf16 precision mode: every NT-form fast launch takes the (one-plane) bf16 kernel, whatever its tile
+  const bool b3 = fast && !b_ncontig && ((big && ft_gemm_b3_enabled()) || ft_gemm_precision() == 1);
   if (b3) {
     (void)ft_launch_gemm_rows_b3(*batch, big, grid, stream);
   } else if (big) {
@@ -692,7 +701,7 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
       fl += 2.0 * t.M * t.N * t.K * t.taps * t.nz;
       sk += (long)t.K * t.taps;
     }
-    log.end(b_ncontig ? "rowsNN" : (b3 ? "rowsB3" : "rowsNT"), maxM, maxN, sk, ntasks, batch->t[0].nz,
+    log.end(b_ncontig ? "rowsNN" : (b3 ? (ft_gemm_precision() == 1 ? "rowsBF" : "rowsB3") : "rowsNT"), maxM, maxN, sk, ntasks, batch->t[0].nz,
             big ? "128" : "64", fl);
   }
   return ft_check_launch("gemm_rows");
@@ -739,7 +748,7 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   log.begin(stream);
   // bf16-split TN form (r-pair packed LDS tiles, ft_gemm_b3.hip): on by default for the 128x128 tile; the 64x64 tile
   // has twice the staging per MFMA and stays on the f32 kernel unless FT_GEMM_B3_TN=1
-  const bool b3 = fast && (tn_b3_mode() == 2 || (tn_b3_mode() == 1 && p.tm == 2));
+  const bool b3 = fast && (ft_gemm_precision() == 1 || tn_b3_mode() == 2 || (tn_b3_mode() == 1 && p.tm == 2));
   if (b3) {
     (void)ft_launch_gemm_tn_b3(t, workspace, p.S, p.rows_per_split, p.tm, grid, stream);
   } else if (p.tm == 2) {

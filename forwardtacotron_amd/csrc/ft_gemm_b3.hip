@@ -13,6 +13,11 @@
 // One LDS stage of 32 k (53 KB for the 128x128 tile -> two workgroups per CU), two barriers per stage; the next
 // stage's global loads are in flight during the MFMAs.  Only the NT form (both operands K-contiguous) exists: callers
 // with an [K][N] operand hand in its transpose.
+//
+// NP = 1 instantiations are the GENUINE bf16 path (BASELINE configs[2], FastPitch "bs=32 bf16"): operands rounded to
+// nearest bf16 while staged (v_cvt_pk_bf16_f32), ONE v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation and fp32
+// outputs -- what autocast-style bf16 matmuls compute.  Selected per process with ft_set_gemm_precision(1); the
+// fp32-exact three-plane form (NP = 3) is the default everywhere else.
 #include "ft_gemm.h"
 
 namespace {
@@ -51,7 +56,14 @@ __device__ __forceinline__ void store_split(unsigned short* row, const float4& v
   *reinterpret_cast<u16x4*>(row + 64) = l;
 }
 
-template <int TM, int TN>
+// NP = 1: round-to-nearest bf16 of 4 floats -> plane 0 only
+__device__ __forceinline__ void store_rn(unsigned short* row, const float4& v) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  bf16x4 r = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+  *reinterpret_cast<bf16x4*>(row) = r;
+}
+
+template <int TM, int TN, int NP>
 __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch batch) {
   const bool zbatch = batch.t[0].nz > 1;           // strided-batch launch: one task, blockIdx.z = instance
   const FtGemmTask& T = batch.t[zbatch ? 0 : blockIdx.z];
@@ -146,9 +158,15 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
   };
   auto store_stage = [&]() {
 #pragma unroll
-    for (int p = 0; p < PA; ++p) store_split(As + (rr + 32 * p) * RS + 4 * kq, ra[p]);
+    for (int p = 0; p < PA; ++p) {
+      if constexpr (NP == 1) store_rn(As + (rr + 32 * p) * RS + 4 * kq, ra[p]);
+      else store_split(As + (rr + 32 * p) * RS + 4 * kq, ra[p]);
+    }
 #pragma unroll
-    for (int p = 0; p < PB; ++p) store_split(Bs + (rr + 32 * p) * RS + 4 * kq, rb[p]);
+    for (int p = 0; p < PB; ++p) {
+      if constexpr (NP == 1) store_rn(Bs + (rr + 32 * p) * RS + 4 * kq, rb[p]);
+      else store_split(Bs + (rr + 32 * p) * RS + 4 * kq, rb[p]);
+    }
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -171,26 +189,31 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
   for (int c = 0; c < nch; ++c) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {                  // two k-steps of 16 per stage
-      bf16x8 a[TM][3], b[TN][3];
+      bf16x8 a[TM][NP], b[TN][NP];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
           a[i][pl] = *reinterpret_cast<const bf16x8*>(ap + 32 * i * RS + 32 * pl + 16 * ks);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
+        for (int pl = 0; pl < NP; ++pl)
           b[j][pl] = *reinterpret_cast<const bf16x8*>(bp + 32 * j * RS + 32 * pl + 16 * ks);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {                // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          if constexpr (NP == 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+            continue;
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][NP - 1], b[j][0], acc[i][j], 0, 0, 0);
+          constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP - 1;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][P2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P1], b[j][P1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][P1], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
         }
     }
@@ -245,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
 // (two 16-B loads), splits them and writes one 16-B piece per plane, conflict-free -- and a fragment is four 4-B reads
 // one pair-row apart (row stride = BM + 8 words puts the two k-halves of a wave 32 banks apart).  [The first version
 // wrote [m][plane][r] rows with 8-B pieces 832 B apart: a 16-way bank conflict that cost what the MFMAs saved.]
-template <int TM, int TN>
+template <int TM, int TN, int NP>
 __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, float* slab, int S, int rows_per_split) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int MQ = BM / 4, NQ = BN / 4;            // column quads per tile
@@ -342,6 +365,18 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
   // rows (even, odd) of 4 columns -> three 16-B pieces of pair-packed bf16
   auto store_pair = [&](unsigned* dst, int plane_stride, const float4& ev, const float4& od) {
     const float e[4] = {ev.x, ev.y, ev.z, ev.w}, o[4] = {od.x, od.y, od.z, od.w};
+    if constexpr (NP == 1) {              // bf16 path: one plane, round to nearest
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      uint4 one;
+      unsigned* po = reinterpret_cast<unsigned*>(&one);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x2 pr = {(__bf16)e[c], (__bf16)o[c]};        // low half = even row, high half = odd row
+        po[c] = __builtin_bit_cast(unsigned, pr);
+      }
+      *reinterpret_cast<uint4*>(dst) = one;
+      return;
+    }
     uint4 hi, mid, lo;
     unsigned* ph = reinterpret_cast<unsigned*>(&hi);
     unsigned* pm = reinterpret_cast<unsigned*>(&mid);
@@ -390,11 +425,11 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
     for (int c = 0; c < nch; ++c) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[TM][3], b[TN][3];
+        bf16x8 a[TM][NP], b[TN][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
+          for (int pl = 0; pl < NP; ++pl) {
             const unsigned* q = ap + pl * PLA + 8 * ks * RWA + 32 * i;
             const uint4 w = make_uint4(q[0], q[RWA], q[2 * RWA], q[3 * RWA]);
             a[i][pl] = __builtin_bit_cast(bf16x8, w);
@@ -402,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) {
+          for (int pl = 0; pl < NP; ++pl) {
             const unsigned* q = bp + pl * PLB + 8 * ks * RWB + 32 * j;
             const uint4 w = make_uint4(q[0], q[RWB], q[2 * RWB], q[3 * RWB]);
             b[j][pl] = __builtin_bit_cast(bf16x8, w);
@@ -411,11 +446,16 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+            if constexpr (NP == 1) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+              continue;
+            }
+            constexpr int P1 = NP > 1 ? 1 : 0, P2 = NP - 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P2], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][P2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P1], b[j][P1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][P1], b[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][P1], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
           }
       }
@@ -446,18 +486,26 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
 
 int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
                          hipStream_t stream) {
-  if (tm == 2)
-    hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<2, 2>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
-  else
-    hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<1, 1>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+  const bool bf16 = ft_gemm_precision() == 1;
+  if (tm == 2) {
+    if (bf16) hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<2, 2, 1>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+    else hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<2, 2, 3>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+  } else {
+    if (bf16) hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<1, 1, 1>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+    else hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<1, 1, 3>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+  }
   return FT_OK;
 }
 
 // NT, FAST (16-B aligned operands, K % 4 == 0) launches only; grid / tile choice made by ft_launch_gemm_rows
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream) {
-  if (big)
-    hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2>), grid, dim3(256), 0, stream, batch);
-  else
-    hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<1, 1>), grid, dim3(256), 0, stream, batch);
+  const bool bf16 = ft_gemm_precision() == 1;
+  if (big) {
+    if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 1>), grid, dim3(256), 0, stream, batch);
+    else hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 3>), grid, dim3(256), 0, stream, batch);
+  } else {
+    if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<1, 1, 1>), grid, dim3(256), 0, stream, batch);
+    else hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<1, 1, 3>), grid, dim3(256), 0, stream, batch);
+  }
   return FT_OK;
 }

@@ -7,6 +7,7 @@ containers only; every computation is a gfx950 kernel behind the C ABI:
 Activations are batch-major channels-last [B,T,d] (the reference's [T,B,d] is only a view convention).
 """
 import copy
+import functools
 import math
 from pathlib import Path
 from typing import Any, Callable, Dict, Optional, Union
@@ -42,6 +43,15 @@ def _bgemm(kind, A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC
     else:
         _lib.call('ft_bgemm_nt', A_ptr, lda, sA0, sA1, B_ptr, ldb, sB0, sB1, C_ptr, ldc, sC0, sC1, M, N, K, nb0, nb1,
                   H._stream())
+
+
+def precision_scoped(fn):
+    """runs a model method under the model's `matmul_dtype` ('fp32' default, 'bf16' = BASELINE configs[2])"""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with H.gemm_precision(getattr(self, 'matmul_dtype', 'fp32')):
+            return fn(self, *a, **k)
+    return wrapped
 
 
 class MHAFn(Function):
@@ -333,6 +343,10 @@ class FastPitch(nn.Module):
                  n_mels: int, padding_value=PAD_VALUE):
         super().__init__()
         self.padding_value = padding_value
+        # 'fp32' (the reference's arithmetic; parity bars) or 'bf16' (BASELINE configs[2]): matmul operands rounded to
+        # bf16, fp32 accumulation; LayerNorm / softmax statistics / losses / optimizer stay fp32.  forward() / generate()
+        # run under it; trainer.TrainStep extends it over backward (hip.gemm_precision for a hand-rolled backward).
+        self.matmul_dtype = 'fp32'
         self.lr = LengthRegulator()
         self.dur_pred = SeriesPredictor(num_chars=num_chars, d_model=durpred_d_model, n_heads=durpred_n_heads,
                                         layers=durpred_layers, d_fft=durpred_d_fft, conv1_kernel=conv1_kernel,
@@ -378,6 +392,7 @@ class FastPitch(nn.Module):
         x = self.postnet(x, src_pad_mask=frame_mask)
         return ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)           # [B,T,n_mels]
 
+    @precision_scoped
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         x = batch['x']
         mel = batch['mel']
@@ -404,6 +419,7 @@ class FastPitch(nn.Module):
             t.record_stream(main)
         return {'mel': x_mel, 'mel_post': x_mel, 'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat}
 
+    @precision_scoped
     def generate(self, x: torch.Tensor, alpha=1.0,
                  pitch_function: Callable[[torch.Tensor], torch.Tensor] = lambda x: x,
                  energy_function: Callable[[torch.Tensor], torch.Tensor] = lambda x: x) -> Dict[str, torch.Tensor]:

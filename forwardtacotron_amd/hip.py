@@ -4,6 +4,7 @@ torch is used here only as the owner of device memory and of the HIP stream; eve
 hand-written gfx950 kernel behind libfwdtaco_hip.so.  All functions require contiguous fp32 CUDA(HIP)
 tensors and raise if handed anything else -- there is no fallback path.
 """
+import contextlib
 import ctypes
 from typing import List, Optional, Sequence
 
@@ -58,6 +59,30 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
     arr = (ctypes.c_void_p * len(ts))(*[_p(t) for t in ts])
     return arr
+
+
+# ---------------------------------------------------------------------------------------------------
+# matmul precision (process-wide switch of the library, include/fwdtaco_hip.h: ft_set_gemm_precision)
+# ---------------------------------------------------------------------------------------------------
+_PRECISIONS = {'fp32': 0, 'bf16': 1}
+
+
+def set_gemm_precision(mode: str) -> str:
+    """'fp32' (default: fp32-exact products) or 'bf16' (operands rounded to bf16, one bf16 MFMA per product, fp32
+    accumulation and outputs); returns the previous mode"""
+    if mode not in _PRECISIONS:
+        raise _lib.FtError(f"gemm precision must be 'fp32' or 'bf16', got {mode!r}")
+    old = _lib.lib().ft_set_gemm_precision(_PRECISIONS[mode])
+    return 'bf16' if old else 'fp32'
+
+
+@contextlib.contextmanager
+def gemm_precision(mode: str):
+    old = set_gemm_precision(mode)
+    try:
+        yield
+    finally:
+        set_gemm_precision(old)
 
 
 # ---------------------------------------------------------------------------------------------------

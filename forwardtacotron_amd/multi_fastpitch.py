@@ -11,7 +11,7 @@ import torch.nn as nn
 from . import _lib
 from . import hip as H
 from . import ops
-from .fastpitch import ForwardTransformer
+from .fastpitch import ForwardTransformer, precision_scoped
 from .model import LengthRegulator, NUM_CHARS_DEFAULT, PAD_VALUE
 
 
@@ -91,6 +91,7 @@ class MultiFastPitch(nn.Module):
         if missing or extra:
             raise TypeError(f'MultiFastPitch(): missing {missing}, unexpected {extra}')
         self.padding_value = padding_value
+        self.matmul_dtype = 'fp32'          # or 'bf16': see fastpitch.FastPitch
         self.lr = LengthRegulator()
         shared = {k: hp[k] for k in ('num_chars', 'conv1_kernel', 'conv2_kernel', 'speaker_emb_dims')}
 
@@ -142,6 +143,7 @@ class MultiFastPitch(nn.Module):
         x = self.postnet(x, src_pad_mask=frame_mask)
         return ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)
 
+    @precision_scoped
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         x = batch['x']
         mel = batch['mel']
@@ -176,6 +178,7 @@ class MultiFastPitch(nn.Module):
         return {'mel': x_mel, 'mel_post': x_mel, 'pitch_cond': pitch_cond_hat, 'dur': dur_hat, 'pitch': pitch_hat,
                 'energy': energy_hat}
 
+    @precision_scoped
     def generate(self, x: torch.Tensor, speaker_emb: torch.Tensor, alpha=1.0,
                  pitch_function: Callable[[torch.Tensor], torch.Tensor] = lambda x: x,
                  energy_function: Callable[[torch.Tensor], torch.Tensor] = lambda x: x) -> Dict[str, torch.Tensor]:

@@ -146,6 +146,7 @@ class TrainStep:
         packs = self._weight_packs()
         packs.refresh()                     # every conv pack / weight transpose of this step, one launch
         H.pack_cache = packs
+        old_precision = H.set_gemm_precision(getattr(model, 'matmul_dtype', 'fp32'))    # forward AND backward
         try:
             pred = model(batch)
             L = self.losses(pred, batch, pitch_target, energy_target)
@@ -163,6 +164,7 @@ class TrainStep:
                 ops.set_grad_sink(None)
         finally:
             H.pack_cache = None
+            H.set_gemm_precision(old_precision)
         cur = torch.cuda.current_stream()
         cur.wait_stream(self.wgrad_stream)
         for st in self.sink.used:               # e.g. the predictors' side stream: its backward wrote gradients too

@@ -30,6 +30,14 @@ int ft_abi_version(void);
 /* host query: CU count and whether device 0 is gfx950 */
 int ft_device_info(int* cu_count, int* is_gfx950);
 
+/* Matmul precision of every GEMM-shaped entry point below (process-wide; returns the previous setting):
+ * 0 (default) = fp32-exact (f32 MFMA, or exact three-way bf16 splits with fp32 accumulation);
+ * 1 = bf16: operands rounded to nearest bf16 on load, ONE bf16 MFMA per product, fp32 accumulation, fp32 outputs --
+ *     BASELINE configs[2] (FastPitch "bf16"); applies to the NT-form aligned launches (Linear / Conv1d forward, their
+ *     data gradients, every weight gradient, attention Q K^T); the rest (NN-form attention products, odd shapes) and all
+ *     non-GEMM kernels (LayerNorm, softmax statistics, losses, optimizer, recurrences) stay fp32. */
+int ft_set_gemm_precision(int bf16);
+
 /* ---- nn.Linear (models/forward_tacotron.py:25,100,108 ; common_layers.py:31-32,83) ------------------ */
 /* Row layouts: the rows of an activation matrix are the (b,t) positions in batch-major order (row = b*T+t,
  * i.e. a contiguous [B,T,C] tensor) unless a `*_tm_B` argument is > 0, in which case that operand is stored

@@ -370,3 +370,78 @@ def test_fastpitch_full_size_properties():
     assert bool(torch.isfinite(out['loss'])) and float(out['grad_norm']) > 0
     worst = max(float((p.detach() - before[n]).abs().max()) for n, p in m.named_parameters())
     assert 0 < worst <= 1e-4 * 1.01
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs[2]: FastPitch with bf16 matmuls (operands rounded to bf16, fp32 accumulation).
+# The reference has NO bf16 path (no autocast anywhere): bf16 parity is defined here, against the
+# fp32 oracle at a stated looser tolerance, and is unpinned by the reference.
+# ---------------------------------------------------------------------------------------------------
+def test_bf16_gemm_rounds_operands_and_accumulates_in_fp32():
+    """the bf16 kernels compute EXACTLY sum_k bf16(a) * bf16(b) in fp32 (to accumulation order): compare with a float64
+    product of the rounded operands (tight) and with the unrounded product (bf16-sized error, not zero)"""
+    from forwardtacotron_amd import hip as H
+    torch.manual_seed(0)
+    for rows, K, N in ((4096, 512, 384), (300, 64, 48), (26912, 80, 256)):
+        x = torch.randn(rows, K, device='cuda')
+        w = torch.randn(N, K, device='cuda')
+        exact = H.linear_fwd(x, w)
+        with H.gemm_precision('bf16'):
+            got = H.linear_fwd(x, w)
+            gdx = H.linear_bwd_data(got, w)
+            gdw = H.linear_bwd_weight(got, x)
+        assert H.set_gemm_precision('fp32') == 'fp32'                     # the context restored the default
+        xr, wr = x.bfloat16().double(), w.bfloat16().double()
+        ref = xr @ wr.t()
+        scale = float(ref.abs().max())
+        assert float((got.double() - ref).abs().max()) < 2e-6 * scale * max(1.0, (K / 64) ** 0.5), (rows, K, N)
+        err = float((got - exact).abs().max())
+        assert 1e-4 * scale < err < 3e-2 * scale, (rows, K, N, err / scale)  # genuinely bf16, not fp32
+        g = got.bfloat16().double()
+        assert float((gdx.double() - g @ wr).abs().max()) < 1e-5 * float((g @ wr).abs().max())
+        assert float((gdw.double() - g.t() @ xr).abs().max()) < 1e-5 * float((g.t() @ xr).abs().max())
+
+
+def _bf16_vs_oracle(cfg, B, Tmax, n_mels, seed, tol_mel, tol_loss):
+    from oracle import fp_oracle as FP
+    from oracle.ft_oracle import synthetic_batch
+    from forwardtacotron_amd.fastpitch import FastPitch
+    from forwardtacotron_amd.trainer import TrainStep
+    torch.manual_seed(seed)
+    m = FastPitch(**cfg)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn(p.shape))
+    P = {k: v.clone() for k, v in m.state_dict().items()}
+    batch = synthetic_batch(B=B, Tmax=Tmax, n_mels=n_mels, max_dur=6, seed=seed)
+    newP, _, info = FP.train_step(P, {}, batch, cfg, TRAIN_CFG, 1e-3, 1)
+    m = m.cuda()
+    m.matmul_dtype = 'bf16'
+    m.eval()
+    with torch.no_grad():
+        ev = m({k: v.clone().cuda() for k, v in batch.items()})
+    m.matmul_dtype = 'fp32'
+    with torch.no_grad():
+        ev32 = m({k: v.clone().cuda() for k, v in batch.items()})
+    d_bf = maxdiff(ev['mel'].cpu(), ev32['mel'].cpu())
+    assert 1e-5 < d_bf < tol_mel, d_bf                     # bf16 really differs from fp32, within the stated tolerance
+    m.matmul_dtype = 'bf16'
+    ts = TrainStep(m, lr=1e-3, train_cfg=TRAIN_CFG)
+    out = ts.step({k: v.clone().cuda() for k, v in batch.items()})
+    ts.check()
+    assert abs(float(out['loss']) - float(info['losses']['loss'])) < tol_loss * max(1.0, float(info['losses']['loss']))
+    gn = float(info['grad_norm'])
+    assert abs(float(out['grad_norm']) - gn) < 0.03 * max(1.0, gn)
+    assert bool(all(torch.isfinite(p).all() for p in m.parameters()))
+    return d_bf
+
+
+def test_fastpitch_bf16_tiny_vs_fp32_oracle():
+    _bf16_vs_oracle(TINY_FP, B=3, Tmax=9, n_mels=10, seed=3, tol_mel=5e-2, tol_loss=5e-3)
+
+
+def test_fastpitch_bf16_mid_size_vs_fp32_oracle():
+    cfg = dict(TINY_FP, durpred_d_model=32, durpred_d_fft=48, durpred_layers=2, pitch_d_model=32, pitch_n_heads=2,
+               pitch_d_fft=40, energy_d_model=24, energy_n_heads=3, energy_d_fft=32, d_model=64, conv1_kernel=9,
+               conv2_kernel=1, prenet_fft=96, prenet_heads=2, postnet_fft=128, postnet_heads=2, n_mels=20)
+    _bf16_vs_oracle(cfg, B=4, Tmax=23, n_mels=20, seed=5, tol_mel=8e-2, tol_loss=5e-3)

@@ -39,6 +39,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-dropout', action='store_true')
+    ap.add_argument('--dtype', choices=['fp32', 'bf16'], default='fp32',
+                    help="bf16: matmul operands rounded to bf16, fp32 accumulation (FastPitch variants; BASELINE configs[2])")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit('needs an MI355X: the hot path has no CPU fallback')
@@ -47,6 +49,10 @@ def main():
     from forwardtacotron_amd.trainer import TrainStep
     torch.manual_seed(0)
     model, cfg = build(args.model, device)
+    if args.dtype == 'bf16':
+        if not hasattr(model, 'matmul_dtype'):
+            raise SystemExit('--dtype bf16 applies to the FastPitch variants (recurrent models stay fp32)')
+        model.matmul_dtype = 'bf16'
     if args.no_dropout:
         for m in model.modules():
             if hasattr(m, 'p'):
@@ -97,7 +103,8 @@ def main():
     line = {'model': args.model, 'mode': args.mode, 'batch': args.batch, 'Tx': args.tokens, 'Tm': Tm,
             'frames': n_frm, 'tokens': n_tok, 'ms_per_step': round(dt * 1e3, 3),
             'frames_per_s': round(n_frm / dt, 1), 'algorithmic_tflops': round(fl / dt / 1e12, 2),
-            'frac_of_f32_mfma_peak': round(fl / dt / 157.3e12, 4), 'dtype': 'f32',
+            'frac_of_f32_mfma_peak': round(fl / dt / 157.3e12, 4),
+            'frac_of_bf16_dense_peak': round(fl / dt / 2500e12, 4), 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16',
             'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
     if args.mode == 'train':
         line['loss'] = round(float(out['loss']), 5)
