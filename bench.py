@@ -214,6 +214,43 @@ def cpu_baseline(model_cfg, train_cfg, budget_s, threads):
             'step_seconds': [round(t, 2) for t in times]}
 
 
+def fastpitch_bf16_record(device, steps=8, warmup=3):
+    """BASELINE configs[2] beside the headline line: the FastPitch train step at bs=32 / Tx=128 / Tm=841 with bf16 matmuls
+    (operands rounded to bf16, one bf16 MFMA per product, fp32 accumulation; LayerNorm / softmax / losses / Adam fp32),
+    priced against the dense bf16 MFMA peak.  Algorithmic FLOPs: SURVEY.md section 8d (94.6 MFLOP per valid frame)."""
+    from forwardtacotron_amd import data
+    from forwardtacotron_amd.fastpitch import FastPitch
+    from forwardtacotron_amd.trainer import TrainStep
+    torch.manual_seed(0)
+    model = FastPitch(**data.FASTPITCH_MODEL).to(device)
+    model.matmul_dtype = 'bf16'
+    ts = TrainStep(model, lr=5e-5, train_cfg=dict(data.SINGLESPEAKER_TRAIN))
+    batch = data.to_device(data.synthetic_batch(B=32, Tmax=128, n_mels=80, seed=0), device)
+    dur0 = batch['dur'].clone()
+    n_frm, n_tok, Tm = int(batch['mel_len'].sum()), int(batch['x_len'].sum()), int(batch['mel_len'].max())
+
+    def step():
+        batch['dur'].copy_(dur0)
+        return ts.step(batch)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fl = data.fastpitch_train_flops(n_tok, n_frm, 128, Tm)
+    return {'workload': 'FastPitch singlespeaker.yaml train step, bs=32, Tx=128, Tm=841, bf16 matmuls (BASELINE configs[2])',
+            'dtype': 'bf16', 'ms_per_step': round(dt * 1e3, 3), 'frames_per_s': round(n_frm / dt, 1), 'steps': steps,
+            'algorithmic_tflops': round(fl / dt / 1e12, 2),
+            'frac_of_bf16_dense_peak': round(fl / dt / (BF16_MFMA_PEAK_TFLOPS * 1e12), 4),
+            'loss': round(float(out['loss']), 5),
+            'parity': 'defined by this repo against the fp32 oracle (tests/test_gpu_fastpitch.py); the reference has no '
+                      'bf16 path'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -223,6 +260,7 @@ def main():
     ap.add_argument('--cpu-budget', type=float, default=120.0, help='seconds of CPU baseline work (N=1, rank 0)')
     ap.add_argument('--cpu-threads', type=int, default=16, help='torch threads of the CPU baseline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-variants', action='store_true', help='skip the FastPitch bf16 record (N=1 only)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -358,6 +396,8 @@ def main():
             'rnn_launches': {'persistent': pers, 'refused_admission': refused},
             'roofline': roof,
         }
+        if world == 1 and not args.no_variants:
+            line['variants'] = {'fastpitch_bf16_train': fastpitch_bf16_record(device)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(model_cfg, train_cfg, args.cpu_budget, args.cpu_threads)
         print(json.dumps(line), flush=True)

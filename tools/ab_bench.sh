@@ -2,7 +2,7 @@
 # same-box A/B of bench.py under different environment settings (one JSON summary line each)
 # usage: bash tools/ab_bench.sh "FT_RNN_LOCAL=1" "FT_RNN_LOCAL=0" ...
 for cfg in "$@"; do
-  env $cfg python bench.py --steps 10 --warmup 3 --no-cpu-baseline --family-steps 2 > /tmp/ab.json 2> /tmp/ab.err || { tail -5 /tmp/ab.err; continue; }
+  env $cfg python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants --family-steps 2 > /tmp/ab.json 2> /tmp/ab.err || { tail -5 /tmp/ab.err; continue; }
   python - "$cfg" <<'PY'
 import json, sys
 d = json.load(open('/tmp/ab.json'))

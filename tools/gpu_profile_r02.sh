@@ -10,7 +10,7 @@ cd $R
 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
 export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --family-steps 0"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants --family-steps 0"
 rocprofv3 --kernel-trace --stats --truncate-kernels --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 echo trace done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --truncate-kernels --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1
