@@ -5,7 +5,6 @@ kernels reached through the C ABI (forwardtacotron_amd.hip).  Activations are ch
 throughout; recurrence outputs are time-major [T,B,C].  torch only owns the memory, the streams and
 the autograd graph.
 """
-import weakref
 from typing import List, Optional
 
 import torch
@@ -438,16 +437,16 @@ class HighwayFn(Function):
 # what the peers have enqueued so far, and the peers wait for the LSTM kernel before they start anything new -- and
 # tell the library (ft_rnn_note_join).  The predictors' 128-step recurrences then overlap with the rest of the trunk
 # (CBHG convolutions, GRUs, weight gradients) instead of with the LSTM.
-_PEER_STREAMS = weakref.WeakSet()      # (a model's side stream dies with the model)
+_PEER_STREAMS = {}                     # raw hipStream_t -> torch.cuda.Stream (torch hands out pooled streams: few, reused)
 
 
 def register_peer_stream(stream) -> None:
-    _PEER_STREAMS.add(stream)
+    _PEER_STREAMS[(stream.device.index, stream.cuda_stream)] = stream
 
 
 def _exclusive_begin():
     cur = torch.cuda.current_stream()
-    peers = [p for p in _PEER_STREAMS if p != cur and p.device == cur.device]
+    peers = [p for (dev, raw), p in _PEER_STREAMS.items() if dev == cur.device.index and raw != cur.cuda_stream]
     for p in peers:
         cur.wait_stream(p)
         H.rnn_note_join(cur, p)
