@@ -58,7 +58,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if warn and verbose:
                 sys.stderr.write(warn)
     if rebuilt or not os.path.exists(LIB):
-        r = subprocess.run([HIPCC, '-shared', '--offload-arch=gfx950', '-o', LIB] + objs,
+        r = subprocess.run([HIPCC, '-shared', '--offload-arch=gfx950', '-Wl,-z,defs', '-o', LIB] + objs,   # undefined symbols fail the build
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')

@@ -421,7 +421,48 @@ ChunkPlan plan_chunks(long rows, int C) {
 
 }  // namespace
 
+// (sum, sum of squares) partials of y[B,Tbuf,C] by the stand-alone pass; returns the number of chunks written
+int ft_bn_stat_partials(const float* y, int B, int Tbuf, int C, int group, double* partial, hipStream_t s) {
+  ChunkPlan p = plan_chunks((long)B * Tbuf, C);
+  if (C % 4 == 0 && (group == 0 || group % 4 == 0) && all16(y))
+    hipLaunchKernelGGL(ft_col_partial4_kernel<0>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, nullptr, nullptr,
+                       nullptr, B, Tbuf, Tbuf, C, group, p.rows_per_chunk, partial);
+  else
+    hipLaunchKernelGGL(ft_col_partial_kernel<0>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, (long)C, nullptr,
+                       nullptr, nullptr, B, Tbuf, Tbuf, C, group, p.rows_per_chunk, partial);
+  return p.nchunks;
+}
+
 extern "C" {
+
+size_t ft_bn_workspace(int B, int Tbuf, int C);
+
+size_t ft_conv_stats_workspace(int B, int Tbuf, int C) {
+  const size_t tiles = (size_t)ft_cdiv((long)B * Tbuf, 128) * C * 2 * sizeof(double);      // one partial per 128-row GEMM tile
+  const size_t chunks = ft_bn_workspace(B, Tbuf, C);
+  return tiles > chunks ? tiles : chunks;
+}
+
+int ft_bn_train_from_partials(const double* partial, int nchunks, const float* y, const float* gamma, const float* beta,
+                              const float* residual, float* out, float* running_mean, float* running_var,
+                              long* num_batches_tracked, float* save_mean, float* save_rstd, int B, int Tbuf, int Tout,
+                              int C, int group, float momentum, float eps, void* stream) {
+  FT_REQUIRE(B > 0 && Tbuf > 0 && C > 0 && Tout <= Tbuf && nchunks >= 1, "bn_train_from_partials: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ft_bn_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, partial, nchunks, B, Tbuf, C, group,
+                     momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_rstd);
+  if (out && Tout > 0) {
+    long total = (long)B * Tout * C;
+    if (C % 4 == 0 && all16(y, save_mean, save_rstd, gamma, beta, residual, out))
+      hipLaunchKernelGGL(ft_bn_apply4_kernel, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, s, (const float4*)y,
+                         (const float4*)save_mean, (const float4*)save_rstd, (const float4*)gamma, (const float4*)beta,
+                         (const float4*)residual, (float4*)out, total / 4, Tbuf, Tout, C / 4);
+    else
+      hipLaunchKernelGGL(ft_bn_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, y, save_mean, save_rstd, gamma,
+                         beta, residual, out, B, Tbuf, Tout, C);
+  }
+  return ft_check_launch("bn_train_from_partials");
+}
 
 size_t ft_bn_workspace(int B, int Tbuf, int C) {
   ChunkPlan p = plan_chunks((long)B * Tbuf, C);

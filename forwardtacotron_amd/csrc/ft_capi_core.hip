@@ -29,6 +29,10 @@ int ft_lr_scan_impl(float*, int, int, int*, int*, hipStream_t);
 int ft_lr_expand_impl(const float*, const int*, float*, int*, int, int, int, int, hipStream_t);
 int ft_lr_bwd_impl(const float*, const int*, float*, int, int, int, int, hipStream_t);
 
+// ft_bn.hip: statistics partials by the stand-alone column pass (C++ linkage), and the partial-buffer size query
+int ft_bn_stat_partials(const float* y, int B, int Tbuf, int C, int group, double* partial, hipStream_t s);
+extern "C" size_t ft_conv_stats_workspace(int B, int Tbuf, int C);
+
 extern "C" {
 
 const char* ft_last_error(void) { return g_err; }
@@ -206,6 +210,59 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
     woff += (long)k * C * Cin;
   }
   return ft_launch_gemm_rows(&b, K, false, (hipStream_t)stream);
+}
+
+// conv (+ReLU) that also leaves the BatchNorm statistics partials of its output behind: from the GEMM's own epilogue
+// when the launch takes the 128x128 split kernel, by the stand-alone column pass otherwise
+
+int ft_conv1d_fwd_stats(const float* x, long ldx, const float* wp, float* y, long ldy, int B, int T, int Cin, int Cout,
+                        int k, int Tout, int relu, double* partial, size_t partial_bytes, int* nchunks,
+                        void* stream) {
+  FT_REQUIRE(k >= 1 && Tout >= 1 && Tout <= T + 1 && nchunks && partial, "conv1d_fwd_stats: bad arguments");
+  FT_REQUIRE(ldy == Cout, "conv1d_fwd_stats: y must be contiguous [B,Tout,Cout]");
+  FT_REQUIRE(partial_bytes >= ft_conv_stats_workspace(B, Tout, Cout), "conv1d_fwd_stats: partial buffer too small");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  conv_fwd_task(b.t[0], x, ldx, wp, y, ldy, B, T, Cin, Cout, k, Tout, relu);
+  b.t[0].stat = partial;
+  b.t[0].stat_ld = Cout;
+  b.t[0].stat_col0 = 0;
+  b.t[0].stat_tvalid = Tout;
+  int rc = ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
+  if (rc) return rc;
+  if (b.stat_fused) {
+    *nchunks = ft_cdiv((long)B * Tout, 128);
+    return FT_OK;
+  }
+  *nchunks = ft_bn_stat_partials(y, B, Tout, Cout, 0, partial, (hipStream_t)stream);
+  return ft_check_launch("conv1d_fwd_stats");
+}
+
+int ft_conv_bank_fwd_stats(const float* x, long ldx, const float* wp_all, float* ybank, int B, int T, int Cin, int C,
+                           int K, int relu, double* partial, size_t partial_bytes, int* nchunks, void* stream) {
+  FT_REQUIRE(K >= 1 && K <= FT_MAX_TASKS && nchunks && partial, "conv_bank_fwd_stats: bad arguments");
+  const int Tout = T + 1;           // the training-mode bank buffer: even-k members own T+1 rows (common_layers.py:97-99)
+  FT_REQUIRE(partial_bytes >= ft_conv_stats_workspace(B, Tout, K * C), "conv_bank_fwd_stats: partial buffer too small");
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  long woff = 0;
+  for (int i = 0; i < K; ++i) {
+    int k = i + 1;
+    conv_fwd_task(b.t[i], x, ldx, wp_all + woff, ybank + (long)i * C, (long)K * C, B, T, Cin, C, k, Tout, relu);
+    b.t[i].stat = partial;
+    b.t[i].stat_ld = K * C;
+    b.t[i].stat_col0 = i * C;
+    b.t[i].stat_tvalid = (k & 1) ? T : T + 1;           // BatchNorm of an odd-k member sees T rows
+    woff += (long)k * C * Cin;
+  }
+  int rc = ft_launch_gemm_rows(&b, K, false, (hipStream_t)stream);
+  if (rc) return rc;
+  if (b.stat_fused) {
+    *nchunks = ft_cdiv((long)B * Tout, 128);
+    return FT_OK;
+  }
+  *nchunks = ft_bn_stat_partials(ybank, B, Tout, K * C, C, partial, (hipStream_t)stream);
+  return ft_check_launch("conv_bank_fwd_stats");
 }
 
 int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,

@@ -45,6 +45,12 @@ struct FtGemmTask {
   // instance z = blockIdx.z -> (z0, z1) = (z / nz1, z % nz1); X += z0*sX0 + z1*sX1 (floats)
   int nz, nz1;
   long sA0, sA1, sB0, sB1, sC0, sC1;
+  // BatchNorm statistics from the epilogue (128x128 bf16-split kernel only; see ft_launch_gemm_rows): per M-tile and
+  // column, (sum, sum of squares) of the stored values (after bias / ReLU) over the tile's rows with t = row % amap.Tlog
+  // < stat_tvalid, as doubles at stat[((long)mtile * stat_ld + stat_col0 + col) * 2 + {0,1}] -- the layout of the
+  // chunked partials ft_bn.hip finalizes.  stat = null: off.
+  double* stat;
+  int stat_ld, stat_col0, stat_tvalid;
 };
 #define FT_MAX_TASKS 16
 struct FtGemmBatch {
@@ -52,6 +58,7 @@ struct FtGemmBatch {
   // chain > 1: tasks 0..chain-1 are ONE product, accumulated in registers: C = sum_i sum_tap shift(A_i) * B_i,tap with
   // task 0's M, N, output and epilogue (conv-bank data gradient: every member adds into the same dx)
   int chain;
+  int stat_fused;       // out: 1 if the launched kernel produced the tasks' BatchNorm statistics
 };
 
 // out_tap[m][n] = sum_r Amap(A)[r][m] * Bmap_tap(B)[r][n],  r over R logical rows   ("TN", split over rows)

@@ -683,6 +683,7 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   // the 64x64 tile gains nothing from the split path (its staging per MFMA is twice the 128-tile's): f32 kernel there
   // bf16 precision mode: every NT-form fast launch takes the (one-plane) bf16 kernel, whatever its tile
   const bool b3 = fast && !b_ncontig && ((big && ft_gemm_b3_enabled()) || ft_gemm_precision() == 1);
+  batch->stat_fused = b3 && big && !chained;      // only the 128x128 split kernel computes BatchNorm statistics
   if (b3) {
     (void)ft_launch_gemm_rows_b3(*batch, big, grid, stream);
   } else if (big) {

@@ -236,26 +236,33 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
     }
   }
 
-  // epilogue: identical to ft_gemm_rows_kernel (same accumulator layout)
+  // epilogue: identical to ft_gemm_rows_kernel (same accumulator layout), plus the optional BatchNorm statistics
   const float* ebias = T.bias;
   const float* escale = T.scale;
   const float* eshift = T.shift;
   const bool erelu = T.relu != 0, eacc = T.accumulate != 0;
   const long ldc = T.ldc, cbst = T.cmap.bstride, ctst = T.cmap.tstride;
   const int cTlog = T.cmap.Tlog;
+  double* const stat = (TM == 2 && TN == 2) ? T.stat : nullptr;
+  const int sTlog = T.amap.Tlog, sTv = T.stat_tvalid;
+  const int srow0 = m0 + wm * 32 * TM + 4 * half;          // first row of this lane; t = row % Tlog tracked without divisions
+  const int stb = stat ? srow0 % sTlog : 0;
+  const bool ssmall = sTlog < 32 * TM;
+  double* sred = reinterpret_cast<double*>(smem);          // [wm 2][128 columns][2] doubles = 4 KB of the (now idle) tiles
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * 32 * TN + 32 * j + l31;
+    const bool col_ok = col < tN;
+    const float bv = (ebias && col_ok) ? ebias[col] : 0.f;
+    const float sc = (escale && col_ok) ? escale[col] : 1.f;
+    const float sh = (escale && col_ok) ? eshift[col] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * 32 * TN + 32 * j + l31;
-      if (col >= tN) continue;
-      const float bv = ebias ? ebias[col] : 0.f;
-      const float sc = escale ? escale[col] : 1.f;
-      const float sh = escale ? eshift[col] : 0.f;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (row >= tM) continue;
+        if (row >= tM || !col_ok) continue;
         long crow = row;
         if (cbst != 0) {
           const int cb = row / cTlog;
@@ -264,11 +271,38 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
         float* cp = TC + crow * ldc + col;
         float v = acc[i][j][e] + bv;
         if (erelu) v = fmaxf(v, 0.f);
+        if (stat) {
+          int tt = stb + (row - srow0);                    // < 2 * Tlog unless Tlog is tiny
+          if (ssmall) tt %= sTlog;
+          else if (tt >= sTlog) tt -= sTlog;
+          if (tt < sTv) {
+            s0 += (double)v;
+            s1 += (double)v * (double)v;
+          }
+        }
         if (escale) v = v * sc + sh;
         if (eacc) v += *cp;
         *cp = v;
       }
     }
+    if (stat) {            // lanes l31 and l31 + 32 hold the two row halves of a column: fold, then across the wm waves
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (half == 0) {
+        double* q = sred + ((wm * 128) + wn * 32 * TN + 32 * j + l31) * 2;
+        q[0] = s0;
+        q[1] = s1;
+      }
+    }
+  }
+  if (stat) {
+    __syncthreads();
+    if (tid < 128 && n0 + tid < tN) {
+      double* o = stat + ((long)blockIdx.x * T.stat_ld + T.stat_col0 + n0 + tid) * 2;
+      o[0] = sred[tid * 2] + sred[(128 + tid) * 2];
+      o[1] = sred[tid * 2 + 1] + sred[(128 + tid) * 2 + 1];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -332,6 +332,49 @@ def conv_bank_fwd(x: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, relu: b
     return y
 
 
+def conv1d_fwd_stats(x: torch.Tensor, wp: torch.Tensor, relu: bool, Tout: int):
+    """conv (+ReLU) whose GEMM epilogue also leaves the BatchNorm statistics partials of y behind
+    (include/fwdtaco_hip.h: ft_conv1d_fwd_stats).  -> (y [B,Tout,Cout], partial buffer, nchunks)"""
+    _chk(x, 'x'); _chk(wp, 'wp')
+    B, T, Cin = x.shape
+    k, Cout, _ = wp.shape
+    y = torch.empty(B, Tout, Cout, device=x.device, dtype=x.dtype)
+    nbytes = _lib.query('ft_conv_stats_workspace', B, Tout, Cout)
+    part = workspace(nbytes, x.device)
+    n = ctypes.c_int(0)
+    _lib.call('ft_conv1d_fwd_stats', _p(x), Cin, _p(wp), _p(y), Cout, B, T, Cin, Cout, k, Tout, int(relu), _p(part),
+              part.numel(), ctypes.byref(n), _stream())
+    return y, part, n.value
+
+
+def conv_bank_fwd_stats(x: torch.Tensor, wp_all: torch.Tensor, K: int, C: int, relu: bool):
+    """training-mode conv bank: ybank [B,T+1,K*C] + the statistics partials of its K BatchNorms"""
+    _chk(x, 'x'); _chk(wp_all, 'wp_all')
+    B, T, Cin = x.shape
+    assert wp_all.numel() == C * Cin * K * (K + 1) // 2
+    y = torch.empty(B, T + 1, K * C, device=x.device, dtype=x.dtype)
+    nbytes = _lib.query('ft_conv_stats_workspace', B, T + 1, K * C)
+    part = workspace(nbytes, x.device)
+    n = ctypes.c_int(0)
+    _lib.call('ft_conv_bank_fwd_stats', _p(x), Cin, _p(wp_all), _p(y), B, T, Cin, C, K, int(relu), _p(part),
+              part.numel(), ctypes.byref(n), _stream())
+    return y, part, n.value
+
+
+def bn_train_from_partials(part: torch.Tensor, nchunks: int, y: torch.Tensor, gamma, beta, running_mean, running_var,
+                           Tout: int, group: int = 0, residual: Optional[torch.Tensor] = None,
+                           momentum: float = None, eps: float = None):
+    """finalize the statistics partials (ordered) + normalise: -> (out [B,Tout,C], save_mean, save_rstd)"""
+    B, Tbuf, C = y.shape
+    out = torch.empty(B, Tout, C, device=y.device, dtype=y.dtype)
+    mean = torch.empty(C, device=y.device, dtype=y.dtype)
+    rstd = torch.empty(C, device=y.device, dtype=y.dtype)
+    _lib.call('ft_bn_train_from_partials', _p(part), nchunks, _p(y), _p(gamma), _p(beta), _p(residual), _p(out),
+              _p(running_mean), _p(running_var), None, _p(mean), _p(rstd), B, Tbuf, Tout, C, group,
+              BN_MOMENTUM if momentum is None else momentum, BN_EPS if eps is None else eps, _stream())
+    return out, mean, rstd
+
+
 def conv_pack_weight_t(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[Cout,Cin,k] -> transposed tap-major [k,Cin,Cout] (weight operand of the data gradient in the NT form)"""
     if out is None and pack_cache is not None:

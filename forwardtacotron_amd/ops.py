@@ -299,9 +299,10 @@ class BatchNormConvFn(Function):
         Cout, _, k = w.shape
         Tbuf = T + (1 if k % 2 == 0 else 0)
         wp = H.conv_pack_weight(w)
-        y = H.conv1d_fwd(x, wp, relu=relu, Tout=Tbuf)
-        out, mean, rstd = H.bn_train_fwd(y, gamma, beta, running_mean, running_var, Tout=T, group=0,
-                                         residual=_c(residual) if residual is not None else None)
+        # the statistics come out of the conv's own GEMM epilogue (128x128 launches) -- no read-back of y for them
+        y, part, nch = H.conv1d_fwd_stats(x, wp, relu=relu, Tout=Tbuf)
+        out, mean, rstd = H.bn_train_from_partials(part, nch, y, gamma, beta, running_mean, running_var, Tout=T,
+                                                   group=0, residual=_c(residual) if residual is not None else None)
         ctx.save_for_backward(x, wp, y, gamma, mean, rstd, w, beta)
         ctx.relu = relu
         ctx.has_res = residual is not None
@@ -345,8 +346,9 @@ class ConvBankFn(Function):
         B, T, Cin = x.shape
         C = ws[0].shape[0]
         wp_all = H.bank_packs(ws, False)
-        ybank = H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T + 1)
-        z, mean, rstd = H.bn_train_fwd(ybank, gamma, beta, running_mean, running_var, Tout=T, group=C)
+        ybank, part, nch = H.conv_bank_fwd_stats(x, wp_all, K, C, relu=True)
+        z, mean, rstd = H.bn_train_from_partials(part, nch, ybank, gamma, beta, running_mean, running_var, Tout=T,
+                                                 group=C)
         out = H.maxpool2_fwd(z)
         ctx.save_for_backward(x, wp_all, ybank, z, gamma, mean, rstd, *params)
         ctx.K, ctx.C = K, C

@@ -189,6 +189,22 @@ int ft_lr_bwd(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm,
  * train fwd: batch statistics (biased var) over valid rows -> save_mean/save_rstd; running stats updated
  * in place (momentum, unbiased var), *num_batches_tracked += 1; out[B,Tout,C] = bn(y)[:, :Tout] (+residual). */
 size_t ft_bn_workspace(int B, int Tbuf, int C);
+/* BatchNormConv with the statistics pass fused into the convolution (north_star: "BatchNormConv fused"): the conv's
+ * GEMM epilogue reduces (sum, sum of squares) of its 128-row output tile per channel -- doubles, fixed order -- into
+ * `partial` ([nchunks][C][2], ft_conv_stats_workspace bytes) while the tile is still in the MFMA accumulators, so the
+ * activation is not read back for the statistics; launches that do not take the 128x128 kernel (token-side shapes) run
+ * the stand-alone column pass instead -- either way *nchunks (HOST int) tells ft_bn_train_from_partials how many partial
+ * rows to finalize (ordered sum; mean / biased var / running stats as ft_bn_train_fwd) before it normalises.
+ * conv1d: y contiguous [B,Tout,Cout].  conv_bank: training-mode bank buffer [B,T+1,K*C]; odd-k members count T rows. */
+size_t ft_conv_stats_workspace(int B, int Tbuf, int C);
+int ft_conv1d_fwd_stats(const float* x, long ldx, const float* wp, float* y, long ldy, int B, int T, int Cin, int Cout,
+                        int k, int Tout, int relu, double* partial, size_t partial_bytes, int* nchunks, void* stream);
+int ft_conv_bank_fwd_stats(const float* x, long ldx, const float* wp_all, float* ybank, int B, int T, int Cin, int C,
+                           int K, int relu, double* partial, size_t partial_bytes, int* nchunks, void* stream);
+int ft_bn_train_from_partials(const double* partial, int nchunks, const float* y, const float* gamma, const float* beta,
+                              const float* residual, float* out, float* running_mean, float* running_var,
+                              long* num_batches_tracked, float* save_mean, float* save_rstd, int B, int Tbuf, int Tout,
+                              int C, int group, float momentum, float eps, void* stream);
 int ft_bn_train_fwd(const float* y, const float* gamma, const float* beta, const float* residual, float* out,
                     float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
                     float* save_rstd, int B, int Tbuf, int Tout, int C, int group, float momentum, float eps,
