@@ -77,7 +77,7 @@ class Probes:
 
 
 def _bank_describe(a, k):
-    x, K, C = a[0], a[2], a[3]
+    x, K, C = a[0], a[2], a[3]                  # hip.conv_bank_fwd_stats(x, wp_all, K, C, relu)
     return {} if tuple(x.shape) + (C, K) == BANK_SHAPE else None
 
 
@@ -299,7 +299,7 @@ def main():
             one_step()
         probes = Probes(_hip)
         if rank == 0:
-            probes.wrap('conv_bank_fwd', _bank_describe)      # two event records per step
+            probes.wrap('conv_bank_fwd_stats', _bank_describe)      # two event records per step
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -379,7 +379,7 @@ def main():
                                      'MFMA, 128x128-tile GEMMs as exact 3-way bf16 splits on bf16 MFMA (fp32-accurate: '
                                      'same parity bars, FT_GEMM_B3=0 switches it off)'},
             'per_gpu': round(value / world, 1), 'loss': round(loss, 5), 'rnn_persistent': rnn_persistent,
-            'rnn_launches': {'persistent': pers, 'refused_admission': refused},
+            'rnn_launches': {'persistent': pers, 'per_step_fallback': refused, 'waited_for_other_stream': _hip.rnn_waited_launches()},
             'roofline': roof,
         }
         if world == 1 and not args.no_variants:

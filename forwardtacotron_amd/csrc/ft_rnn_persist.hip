@@ -964,7 +964,7 @@ PersistWs carve_ws_rs(void* ws, int ngrp, int nchunks) {
 
 constexpr int MAX_DEV = 16;
 unsigned g_max_spins = MAX_SPINS_DEFAULT;
-long g_n_persistent = 0, g_n_refused = 0;
+long g_n_persistent = 0, g_n_refused = 0, g_n_waited = 0;
 
 int current_device() {
   int dev = 0;
@@ -982,10 +982,12 @@ int current_device() {
 // device, so "unfinished" launches pile up per stream: a launch on stream s is admitted while
 //     d + sum over the OTHER streams of (the largest d among that stream's unfinished launches) <= 0.75
 // (a quarter is kept back: a CU left with room for half a workgroup helps nobody), or -- with nothing unfinished on
-// other streams -- while d <= 1.  ft_rnn_note_join tells the bookkeeping that a stream has waited for another (the
-// joined stream's earlier launches then precede everything the waiting stream does and no longer count against it).
-// One event per launch, retired by query; a refused launch runs the per-step kernels (always safe).  Non-persistent
-// kernels (GEMMs, RCCL) only delay residency: they finish without waiting for us.
+// other streams -- while d <= 1.  A launch that does not fit beside the others is NOT demoted to the per-step kernels
+// (which round differently: results would depend on timing): its stream is made to wait, on the device, for the
+// conflicting launches' events, and it runs persistent afterwards.  ft_rnn_note_join tells the bookkeeping about waits
+// the caller inserted itself (the joined stream's earlier launches then precede everything the waiting stream does and
+// no longer count against it).  One event per launch, retired by query.  Only a grid that does not fit the chip even
+// alone (d > 1) runs per-step.  Non-persistent kernels (GEMMs, RCCL) only delay residency: they finish without us.
 struct Flight {
   hipEvent_t ev;
   hipStream_t stream;
@@ -1039,8 +1041,21 @@ bool admit(double d, hipStream_t stream) {
     if (first) others += mx;
   }
   const double scale = env_int("FT_RNN_ADMIT_PCT", 100) / 100.0;
-  const bool fits = others == 0.0 ? d <= 1.0 * scale : d + others <= 0.75 * scale;
-  if (!fits) return false;
+  if (d > 1.0 * scale) return false;             // does not fit the chip even alone: per-step kernels
+  const bool fits = others == 0.0 || d + others <= 0.75 * scale;
+  if (!fits) {
+    // Not beside what the other streams may still be running: make THIS stream wait for those launches (device-side
+    // wait on their events; the host does not block) and launch afterwards.  Always the same kernel, whatever the
+    // timing -- a fallback to the per-step kernels here would make results depend on when the host happened to look
+    // (they round differently: f32 MFMA against the exact bf16 split) -- and waits only follow enqueue order, so they
+    // cannot form a cycle.
+    for (Flight& f : fl)
+      if (counts(f)) {
+        (void)hipStreamWaitEvent(stream, f.ev, 0);
+        f.joined_by.push_back(stream);
+      }
+    ++g_n_waited;
+  }
   return true;
 }
 
@@ -1125,7 +1140,10 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   const int H = a.H, B = a.B;
   if (!a.vec || H % 16 != 0) return -1;
   const int ngroups = H / 16;
-  const int NW = ngroups > 16 ? 8 : 4;
+  int NW = ngroups > 16 ? 8 : 4;
+  // 4-wave workgroups for the widest layer too (H = 512: each wave keeps 4 of the 16 k-blocks): 256-thread workgroups
+  // run two per CU, so the 64 workgroups of a (direction, batch group) group fit ONE XCD and hand over through its L2
+  if (NW == 8 && G == 4 && H % 32 == 0 && ft_cdiv(H / 32, 4) <= GCH / 2 && env_int("FT_RNN_FWD_NW4", 1)) NW = 4;
   if (ft_cdiv(ngroups, NW) > GCH) return -1;
   const bool b3 = H % 32 == 0 && ft_cdiv(H / 32, NW) <= GCH / 2 && env_int("FT_RNN_B3", 1);   // bf16 pipe (exact split)
   // 16 units per workgroup where 8 would need more than the 32 workgroups per group one XCD can host (H = 512): the
@@ -1296,6 +1314,8 @@ int ft_rnn_counters(long* persistent_launches, long* refused_launches) {
   if (refused_launches) *refused_launches = g_n_refused;
   return FT_OK;
 }
+
+int ft_rnn_waited_launches(void) { return (int)g_n_waited; }
 
 int ft_rnn_mode_counts(long* xcd_local_groups, long* agent_scope_groups) {
   unsigned* w = ft_rnn_fault_word();

@@ -807,10 +807,15 @@ def rnn_mode_counts():
 
 
 def rnn_counters():
-    """(launches that ran in the persistent form, launches refused admission -> per-step kernels) since load"""
+    """(launches that ran in the persistent form, launches that cannot fit the chip -> per-step kernels) since load"""
     a, b = ctypes.c_long(0), ctypes.c_long(0)
     _lib.call('ft_rnn_counters', ctypes.byref(a), ctypes.byref(b))
     return a.value, b.value
+
+
+def rnn_waited_launches() -> int:
+    """persistent launches whose stream first had to wait (on the device) for another stream's persistent launches"""
+    return int(_lib.query('ft_rnn_waited_launches'))
 
 
 def gru_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool):

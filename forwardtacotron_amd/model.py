@@ -127,11 +127,22 @@ class BatchNormConv(nn.Module):
             return ops.BatchNormConvFn.apply(x, self.conv.weight, bn.weight, bn.bias, residual, bn.running_mean,
                                              bn.running_var, self.relu is True)
         # eval: BatchNorm folds into the conv epilogue (scale/shift after the ReLU)
+        _eval_needs_no_grad(x, self.conv.weight)
         scale, shift = H.bn_fold_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         wp = H.conv_pack_weight(self.conv.weight)
         acc = _c_clone(residual) if residual is not None else None
         return H.conv1d_fwd(x.contiguous(), wp, relu=self.relu is True, Tout=x.shape[1], scale=scale, shift=shift,
                             accumulate_into=acc)
+
+
+def _eval_needs_no_grad(x: torch.Tensor, w: torch.Tensor) -> None:
+    """The eval-mode BatchNormConv / conv-bank path is raw kernel launches (BatchNorm folded into the convolution's
+    epilogue): it records no autograd graph.  The reference's eval forward IS differentiable; rather than hand back
+    tensors that silently carry no gradient, refuse the combination (the reference's own eval call sites --
+    evaluate(), generate(), create_gta_features -- all run under torch.no_grad())."""
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        raise H._lib.FtError('eval-mode forward is not differentiable here (BatchNorm is folded into the convolution '
+                             'epilogue): call it under torch.no_grad(), or use model.train() for gradients')
 
 
 def _c_clone(t: torch.Tensor) -> torch.Tensor:
@@ -195,6 +206,7 @@ class CBHG(nn.Module):
             y = ops.ConvBankFn.apply(x, K, gamma, beta, rm, rv, *ws, *gs, *bs)
         else:
             B, T, Cin = x.shape
+            _eval_needs_no_grad(x, self.conv1d_bank[0].conv.weight)
             scale, shift = H.bn_fold_eval(gamma, beta, rm, rv, self.conv1d_bank[0].bnorm.eps)
             wp_all = torch.cat([H.conv_pack_weight(m.conv.weight).reshape(-1) for m in self.conv1d_bank])
             y = H.maxpool2_fwd(H.conv_bank_fwd(x, wp_all, K, C, relu=True, Tout=T, scale=scale, shift=shift))
@@ -363,7 +375,6 @@ class ForwardTacotron(nn.Module):
             self._streams = {}
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
-            ops.register_peer_stream(self._streams[key])      # persistent recurrences run on it beside the trunk's
         return self._streams[key]
 
     def generate(self, x: torch.Tensor, alpha=1.0,

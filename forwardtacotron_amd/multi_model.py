@@ -232,7 +232,6 @@ class MultiForwardTacotron(nn.Module):
             self._streams = {}
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
-            ops.register_peer_stream(self._streams[key])      # persistent recurrences run on it beside the trunk's
         return self._streams[key]
 
     def get_step(self) -> int:

@@ -431,36 +431,6 @@ class HighwayFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
-# Streams that may carry persistent recurrences beside the current one (a model registers its predictor side stream).
-# The big LSTM kernels need every CU of the XCDs they run on (one 8-wave workgroup per CU, ~200 registers per lane), so
-# the library admits them in the persistent form only while no other stream has an unfinished persistent launch
-# (include/fwdtaco_hip.h, ft_rnn_workspace).  The host enqueues far ahead of the device, so "unfinished" would almost
-# always be true: the LSTM ops therefore JOIN the peer streams around their launch -- the current stream waits for
-# what the peers have enqueued so far, and the peers wait for the LSTM kernel before they start anything new -- and
-# tell the library (ft_rnn_note_join).  The predictors' 128-step recurrences then overlap with the rest of the trunk
-# (CBHG convolutions, GRUs, weight gradients) instead of with the LSTM.
-_PEER_STREAMS = {}                     # raw hipStream_t -> torch.cuda.Stream (torch hands out pooled streams: few, reused)
-
-
-def register_peer_stream(stream) -> None:
-    _PEER_STREAMS[(stream.device.index, stream.cuda_stream)] = stream
-
-
-def _exclusive_begin():
-    cur = torch.cuda.current_stream()
-    peers = [p for (dev, raw), p in _PEER_STREAMS.items() if dev == cur.device.index and raw != cur.cuda_stream]
-    for p in peers:
-        cur.wait_stream(p)
-        H.rnn_note_join(cur, p)
-    return cur, peers
-
-
-def _exclusive_end(cur, peers) -> None:
-    for p in peers:
-        p.wait_stream(cur)
-        H.rnn_note_join(p, cur)
-
-
 def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx):
     """Shared tail of the GRU/LSTM backward: weight / bias / input gradients from the per-step
     pre-activation gradients (dxp wrt input projection, dhp wrt hidden projection).
@@ -529,9 +499,7 @@ class BiLSTMFn(Function):
         Hh = w_hh_f.shape[1]
         train = any(ctx.needs_input_grad)
         xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
-        cur, peers = _exclusive_begin()
         raw, cst, gates = H.lstm_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens, Hh, save_gates=train)
-        _exclusive_end(cur, peers)
         if train:
             ctx.save_for_backward(x, raw, cst, gates, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
                                   b_ih_r, b_hh_r)
@@ -547,10 +515,8 @@ class BiLSTMFn(Function):
         Hh = ctx.Hh
         dout_tm = H.bt_transpose(_c(dout), True)
         pend = flush_begin()
-        cur, peers = _exclusive_begin()
         dg = H.lstm_bwd(dout_tm, raw, cst, gates, H.transpose2d(params[1]),
                         H.transpose2d(params[5]), lens if ctx.has_lens else None, Hh)
-        _exclusive_end(cur, peers)
         flush_end(pend)
         dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, params, ctx.needs_input_grad[0])
         return (dx, None, None, *g)

@@ -316,8 +316,10 @@ int ft_rnn_note_join(void* waiting_stream, void* joined_stream);
 /* (direction, batch group) groups of persistent launches that ran the XCD-local hand-off / the agent-scope one since
  * the library loaded (synchronises the device) */
 int ft_rnn_mode_counts(long* xcd_local_groups, long* agent_scope_groups);
-/* launches that ran in the persistent form / that were refused admission (and ran per-step) since the library loaded */
+/* launches that ran in the persistent form / that did not fit the chip even alone (and ran per-step) since the library
+ * loaded; ft_rnn_waited_launches: persistent launches whose stream was first made to wait for other streams' */
 int ft_rnn_counters(long* persistent_launches, long* refused_launches);
+int ft_rnn_waited_launches(void);
 int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
                float* out, float* gates, int B, int T, int H, void* workspace, size_t workspace_bytes,
                void* stream);

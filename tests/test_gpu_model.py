@@ -479,6 +479,19 @@ def test_torchscript_generate_jit(ft, tmp_path):
         assert set(mod(x).keys()) == {'mel', 'mel_post', 'dur', 'pitch', 'energy'}
 
 
+def test_eval_forward_with_autograd_enabled_is_refused(ft):
+    """the eval path records no autograd graph (BatchNorm folded into the conv epilogue): asked for gradients it must
+    raise, not return tensors that silently carry none"""
+    model, ops, hip = ft
+    M = load_npz('tiny_model.npz')
+    m = load_sd(model.ForwardTacotron(**TINY), sub(M, 'sd/')).cuda().eval()
+    batch = cuda_batch(sub(M, 'batch/'))
+    with pytest.raises(hip._lib.FtError, match='not differentiable'):
+        m(batch)
+    with torch.no_grad():
+        m(cuda_batch(sub(M, 'batch/')))
+
+
 def test_cpu_tensors_are_refused(ft):
     model, ops, hip = ft
     m = model.ForwardTacotron(**TINY)
