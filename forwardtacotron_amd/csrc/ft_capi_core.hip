@@ -215,6 +215,16 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
 // conv (+ReLU) that also leaves the BatchNorm statistics partials of its output behind: from the GEMM's own epilogue
 // when the launch takes the 128x128 split kernel, by the stand-alone column pass otherwise
 
+// FT_BN_FUSED_STATS=0: always the stand-alone statistics pass (A/B aid)
+static bool stats_in_epilogue() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FT_BN_FUSED_STATS");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 int ft_conv1d_fwd_stats(const float* x, long ldx, const float* wp, float* y, long ldy, int B, int T, int Cin, int Cout,
                         int k, int Tout, int relu, double* partial, size_t partial_bytes, int* nchunks,
                         void* stream) {
@@ -224,13 +234,13 @@ int ft_conv1d_fwd_stats(const float* x, long ldx, const float* wp, float* y, lon
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
   conv_fwd_task(b.t[0], x, ldx, wp, y, ldy, B, T, Cin, Cout, k, Tout, relu);
-  b.t[0].stat = partial;
+  b.t[0].stat = stats_in_epilogue() ? partial : nullptr;
   b.t[0].stat_ld = Cout;
   b.t[0].stat_col0 = 0;
   b.t[0].stat_tvalid = Tout;
   int rc = ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
   if (rc) return rc;
-  if (b.stat_fused) {
+  if (b.stat_fused && stats_in_epilogue()) {
     *nchunks = ft_cdiv((long)B * Tout, 128);
     return FT_OK;
   }
@@ -249,7 +259,7 @@ int ft_conv_bank_fwd_stats(const float* x, long ldx, const float* wp_all, float*
   for (int i = 0; i < K; ++i) {
     int k = i + 1;
     conv_fwd_task(b.t[i], x, ldx, wp_all + woff, ybank + (long)i * C, (long)K * C, B, T, Cin, C, k, Tout, relu);
-    b.t[i].stat = partial;
+    b.t[i].stat = stats_in_epilogue() ? partial : nullptr;
     b.t[i].stat_ld = K * C;
     b.t[i].stat_col0 = i * C;
     b.t[i].stat_tvalid = (k & 1) ? T : T + 1;           // BatchNorm of an odd-k member sees T rows
@@ -257,7 +267,7 @@ int ft_conv_bank_fwd_stats(const float* x, long ldx, const float* wp_all, float*
   }
   int rc = ft_launch_gemm_rows(&b, K, false, (hipStream_t)stream);
   if (rc) return rc;
-  if (b.stat_fused) {
+  if (b.stat_fused && stats_in_epilogue()) {
     *nchunks = ft_cdiv((long)B * Tout, 128);
     return FT_OK;
   }
