@@ -59,25 +59,33 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-// exact 3-way bf16 split of 8 fp32 values (x = hi + mid + lo, truncation splits; see ft_gemm_b3.hip): the recurrent
-// matmuls then run as six v_mfma_f32_16x16x32_bf16 per 32-k block instead of eight v_mfma_f32_16x16x4_f32 --
-// 2.67x fewer matrix-pipe cycles at fp32-class accuracy (B3 variants of the kernels below; need H % 32 == 0)
+// exact 3-way bf16 split of 8 fp32 values (x = hi + mid + lo to 2^-27 |x|; see ft_gemm_b3.hip): the recurrent matmuls
+// then run as six v_mfma_f32_16x16x32_bf16 per 32-k block instead of eight v_mfma_f32_16x16x4_f32 -- 2.67x fewer
+// matrix-pipe cycles at fp32-class accuracy (B3 variants of the kernels below; need H % 32 == 0).  Round-to-nearest
+// pieces through v_cvt_pk_bf16_f32 (two values per instruction, already packed): hi = rn(x), r1 = x - hi (exact),
+// mid = rn(r1), r2 = r1 - mid (exact), lo = rn(r2).  One definition for every place a value is split -- operands
+// split by the consumer (agent-scope hand-off) and values split by the producer (XCD-local granules) give the same bits.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rn_pack(float a, float b) {
+  const bf16x2v p = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = rn_pack(a, b);
+  const float a1 = a - __uint_as_float(hi << 16), b1 = b - __uint_as_float(hi & 0xFFFF0000u);
+  mid = rn_pack(a1, b1);
+  const float a2 = a1 - __uint_as_float(mid << 16), b2 = b1 - __uint_as_float(mid & 0xFFFF0000u);
+  lo = rn_pack(a2, b2);
+}
 __device__ __forceinline__ void split8(const float4& v0, const float4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-  u16x8 h, m, l;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const unsigned hb = __float_as_uint(f[i]) & 0xFFFF0000u;
-    const float r1 = f[i] - __uint_as_float(hb);
-    const unsigned mb = __float_as_uint(r1) & 0xFFFF0000u;
-    const float r2 = r1 - __uint_as_float(mb);
-    h[i] = (unsigned short)(hb >> 16);
-    m[i] = (unsigned short)(mb >> 16);
-    l[i] = (unsigned short)(__float_as_uint(r2) >> 16);
-  }
-  hi = __builtin_bit_cast(bf16x8, h);
-  mid = __builtin_bit_cast(bf16x8, m);
-  lo = __builtin_bit_cast(bf16x8, l);
+  unsigned h[4], m[4], l[4];
+  split_pair(v0.x, v0.y, h[0], m[0], l[0]);
+  split_pair(v0.z, v0.w, h[1], m[1], l[1]);
+  split_pair(v1.x, v1.y, h[2], m[2], l[2]);
+  split_pair(v1.z, v1.w, h[3], m[3], l[3]);
+  hi = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+  mid = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+  lo = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
 }
 __device__ __forceinline__ void mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4& acc) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);      // small terms first
@@ -146,6 +154,61 @@ __device__ __forceinline__ bool poll_flag(const unsigned* f, unsigned step, unsi
       if (++spins > max_spins) ok = false;
   }
   return __all(ok);
+}
+
+// XCD-local mode of the bf16-split kernels: the hand-off unit is an 8-byte GRANULE {hi, mid, lo, tag} -- the value already
+// split into its three bf16 pieces by the PRODUCER (once, instead of by every consumer of every step) and a 16-bit tag
+// = (step + 1) & 0xffff.  One 8-byte store is one indivisible memory transaction, so the tag validates the value it
+// travels with: no drain, no flag store, no flag poll -- a consumer loads the granules of its operand slice (L1-bypassing
+// loads, served by the XCD's L2), and reloads a block while any of its tags is not the awaited one.  Granules live in an
+// area of their own behind the two fp32 parities (never written with anything else; zeroed per launch), in two parities
+// like the fp32 exchange (a slot is rewritten every second step: a stale tag is the awaited one minus 2).
+struct Gran {
+  u32x4 v[4];           // the 8 granules of one lane's fragment (k = 8q .. 8q+7 of one row): v[j] = granules 2j, 2j+1
+};
+constexpr int GL_AUX = 16 | (int)0x80000000;        // sc1 + volatile (a poll must really re-load)
+__device__ __forceinline__ void gran_load(Gran& g, __amdgpu_buffer_rsrc_t rs, unsigned offA, unsigned offB) {
+  g.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA, 0, GL_AUX);
+  g.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, offA + 16, 0, GL_AUX);
+  g.v[2] = __builtin_amdgcn_raw_buffer_load_b128(rs, offB, 0, GL_AUX);
+  g.v[3] = __builtin_amdgcn_raw_buffer_load_b128(rs, offB + 16, 0, GL_AUX);
+}
+__device__ __forceinline__ bool gran_ok(const Gran& g, unsigned want_hi) {      // want_hi = tag << 16
+  unsigned x = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x |= (g.v[j].y ^ want_hi) | (g.v[j].w ^ want_hi);
+  return (x & 0xFFFF0000u) == 0u;
+}
+__device__ __forceinline__ void gran_unpack(const Gran& g, bf16x8 (&a3)[3]) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = __builtin_amdgcn_perm(g.v[j].z, g.v[j].x, 0x05040100u);        // low halves:  hi(2j) | hi(2j+1) << 16
+    m[j] = __builtin_amdgcn_perm(g.v[j].z, g.v[j].x, 0x07060302u);        // high halves: mid
+    l[j] = __builtin_amdgcn_perm(g.v[j].w, g.v[j].y, 0x05040100u);        // low halves of the second dwords: lo
+  }
+  a3[0] = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+  a3[1] = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+  a3[2] = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+}
+// one value -> its granule (the same round-to-nearest split as split8)
+__device__ __forceinline__ unsigned long long gran_make(float x, unsigned tag) {
+  const unsigned hi = rn_pack(x, 0.f) & 0xFFFFu;
+  const float r1 = x - __uint_as_float(hi << 16);
+  const unsigned mid = rn_pack(r1, 0.f) & 0xFFFFu;
+  const float r2 = r1 - __uint_as_float(mid << 16);
+  const unsigned lo = rn_pack(r2, 0.f) & 0xFFFFu;
+  return (unsigned long long)(hi | (mid << 16)) | ((unsigned long long)(lo | (tag << 16)) << 32);
+}
+// waits (bounded) until the block's granules all carry the awaited tag; returns false on timeout (wave-uniform)
+__device__ __forceinline__ bool gran_wait(Gran& g, __amdgpu_buffer_rsrc_t rs, unsigned offA, unsigned offB, unsigned want_hi,
+                                          unsigned max_spins) {
+  unsigned spins = 0;
+  while (!__all(gran_ok(g, want_hi))) {
+    if (++spins > max_spins) return false;
+    gran_load(g, rs, offA, offB);
+  }
+  return max_spins != 0;                  // 0 = fault injection
 }
 
 // step 1, wave 0, after the agent-scope arrival wait: did every workgroup of the group report my XCC id?
@@ -280,8 +343,54 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       for (int e = 0; e < 4; ++e) acc[nt][e] = 0.f;
     float4 av[B3 ? 1 : GCH];
     float4 aw[B3 ? BCH : 1][2];
-    if (s > 0) {
-      if (local) {       // every wave waits for the producers of its own slice; a timeout is acted on at the next barrier
+    // next step's x projection (hoisted above the hand-off: its latency hides behind the wait)
+    float xn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) xn[g] = 0.f;
+    if (cthr && s + 1 < L) {
+      const int cn = d == 0 ? s + 1 : L - 2 - s;
+      const float* xr = a.xp + ((long)cn * a.B + cb) * ldx + (long)d * G * H + cun;
+#pragma unroll
+      for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
+    }
+    const bool gl = local;              // protocol of THIS step's operands (the mode may change below, at s == 1)
+    if (s > 0 && gl && B3) {
+      // XCD-local, bf16-split: granules (file header).  Block c+1 is requested before block c is consumed; a block whose
+      // tags are not all the awaited ones is re-loaded until they are.
+      if constexpr (B3) {
+        const unsigned want_hi = ((unsigned)s & 0xFFFFu) << 16;
+        const unsigned gbase = (unsigned)(((long)2 * par_floats * 4) + ((long)((s - 1) & 1) * par_floats + base_floats) * 8);
+        auto offs = [&](int c, unsigned& oa, unsigned& ob) {
+          const long quad = 8 * (kb0 + c) + 2 * q;
+          oa = gbase + (unsigned)((quad * MB + l15) * 4 * 8);
+          ob = gbase + (unsigned)(((quad + 1) * MB + l15) * 4 * 8);
+        };
+        Gran gr[2];
+        unsigned oa, ob;
+        if (kb0 < kb1) {
+          offs(0, oa, ob);
+          gran_load(gr[0], rs, oa, ob);
+        }
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < BCH; ++c)
+          if (kb0 + c < kb1) {
+            if (c + 1 < BCH && kb0 + c + 1 < kb1) {
+              unsigned na, nb;
+              offs(c + 1, na, nb);
+              gran_load(gr[(c + 1) & 1], rs, na, nb);
+            }
+            offs(c, oa, ob);
+            ok = gran_wait(gr[c & 1], rs, oa, ob, want_hi, geo.max_spins) && ok;
+            bf16x8 a3[3];
+            gran_unpack(gr[c & 1], a3);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mfma6(a3, bw[nt][c], acc[nt]);
+          }
+        if (!ok && lane == 0) s_fail = 1;
+      }
+    } else if (s > 0) {
+      if (gl) {          // XCD-local, f32 MFMA form: flag words; every wave waits for the producers of its own slice
         if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
       } else {
         if (wave == 0) {
@@ -310,6 +419,12 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
             const long quad = 4 * (g0 + c) + q;
             av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
           }
+#pragma unroll
+        for (int c = 0; c < GCH; ++c)
+          if (g0 + c < g1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mfma4(av[c], bv[nt][c], acc[nt]);
+          }
       } else {
 #pragma unroll
         for (int c = 0; c < BCH; ++c)
@@ -318,27 +433,6 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
             aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
             aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
           }
-      }
-    }
-    // next step's x projection, requested behind the exchange loads
-    float xn[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) xn[g] = 0.f;
-    if (cthr && s + 1 < L) {
-      const int cn = d == 0 ? s + 1 : L - 2 - s;
-      const float* xr = a.xp + ((long)cn * a.B + cb) * ldx + (long)d * G * H + cun;
-#pragma unroll
-      for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
-    }
-    if (s > 0) {
-      if constexpr (!B3) {
-#pragma unroll
-        for (int c = 0; c < GCH; ++c)
-          if (g0 + c < g1) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mfma4(av[c], bv[nt][c], acc[nt]);
-          }
-      } else {
 #pragma unroll
         for (int c = 0; c < BCH; ++c)
           if (kb0 + c < kb1) {
@@ -385,11 +479,19 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       }
       hprev = hnew;
       // exchange block [CW*chunk + jq][16][4] of parity s&1, before anything else
-      float* xw = xb + (long)(s & 1) * par_floats + base_floats + (((long)CW * chunk + jq) * MB + ci) * 4 + jj;
-      if (local) __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain: stays in the XCD's L2
-      else __hip_atomic_store(xw, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // write-through (sc1)
+      const long xe = (long)(s & 1) * par_floats + base_floats + (((long)CW * chunk + jq) * MB + ci) * 4 + jj;
+      if (local && B3) {                // granule {hi, mid, lo, tag = s + 1}: one 8-byte plain store, nothing else to signal
+        unsigned long long* gp = reinterpret_cast<unsigned long long*>(xb + 2 * par_floats) + xe;
+        __hip_atomic_store(gp, gran_make(hnew, (unsigned)(s + 1) & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      } else if (local) {
+        __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain: stays in the XCD's L2
+      } else {
+        __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
+      }
     }
-    if (geo.sig_per_wave) {
+    if (local && B3) {
+      // granules carry their own tags
+    } else if (geo.sig_per_wave) {
       if (sthr) {                                          // the cell waves, wave-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -937,7 +1039,7 @@ struct PersistWs {
   unsigned* cnt;
   size_t sync_bytes, xb_bytes, total_bytes;
 };
-// workspace = [arrival counters | flag words | XCC ids | exchange buffer]; the sync region (and, for the all-gather
+// workspace = [arrival counters | flag words | XCC ids | exchange buffer (fp32 parities, granule parities)]; the sync region (and, for the all-gather
 // forms, the exchange buffer) is zeroed per call from the allocation's start (the fault word is NOT in here: it is the
 // device-global g_rnn_fault, which launches never touch)
 size_t sync_region_bytes(int ngrp) { return (size_t)ngrp * (NSH * CSTRIDE + NFLAG + NXCC) * sizeof(unsigned); }
@@ -945,7 +1047,8 @@ PersistWs carve_ws(void* ws, int ngrp, int K) {
   PersistWs p;
   p.sync_bytes = sync_region_bytes(ngrp);
   p.cnt = (unsigned*)ws;
-  p.xb_bytes = (size_t)2 * ngrp * (K / 4) * MB * 4 * sizeof(float);
+  // two fp32 parities, then the granule area of the XCD-local split kernels (two parities of 8-byte granules)
+  p.xb_bytes = (size_t)3 * 2 * ngrp * (K / 4) * MB * 4 * sizeof(float);
   p.xb = (float*)((char*)ws + p.sync_bytes);
   p.total_bytes = p.sync_bytes + p.xb_bytes;
   return p;
