@@ -480,9 +480,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       hprev = hnew;
       // exchange block [CW*chunk + jq][16][4] of parity s&1, before anything else
       const long xe = (long)(s & 1) * par_floats + base_floats + (((long)CW * chunk + jq) * MB + ci) * 4 + jj;
-      if (local && B3) {                // granule {hi, mid, lo, tag = s + 1}: one 8-byte plain store, nothing else to signal
-        unsigned long long* gp = reinterpret_cast<unsigned long long*>(xb + 2 * par_floats) + xe;
-        __hip_atomic_store(gp, gran_make(hnew, (unsigned)(s + 1) & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (local && B3) {                // (granule mode: stored below, for EVERY row)
       } else if (local) {
         __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain: stays in the XCD's L2
       } else {
@@ -490,7 +488,15 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       }
     }
     if (local && B3) {
-      // granules carry their own tags
+      // granule {hi, mid, lo, tag = s + 1}: one 8-byte plain store per (row, unit), nothing else to signal.  EVERY row
+      // slot is written every step -- rows beyond the batch and finished items as zeros -- because a consumer accepts a
+      // block only once all its tags are the awaited ones
+      if (sthr) {
+        const long xe = (long)(s & 1) * par_floats + base_floats + (((long)CW * chunk + jq) * MB + ci) * 4 + jj;
+        unsigned long long* gp = reinterpret_cast<unsigned long long*>(xb + 2 * par_floats) + xe;
+        __hip_atomic_store(gp, gran_make(cact ? hnew : 0.f, (unsigned)(s + 1) & 0xFFFFu), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     } else if (geo.sig_per_wave) {
       if (sthr) {                                          // the cell waves, wave-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
