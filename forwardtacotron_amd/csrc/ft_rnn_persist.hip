@@ -237,12 +237,16 @@ __device__ __forceinline__ bool decode(const Geom& g, int& d, int& bgp, int& chu
 // UB = 8 (the UB = 16 instantiation for the 512-wide LSTM -- 32 workgroups per group, one XCD -- exists but loses to
 // register spills, see fwd_persistent)
 // ---------------------------------------------------------------------------------------------------
-template <int G, int NW, bool B3, int UB>
+template <int G, int NW, bool B3, int UB, int BC>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                      unsigned* fault, unsigned xb_bytes) {
   // UB hidden units (all G gates) per workgroup: G*UB columns = NT tiles of 16; cell waves = UB / 4 (one [16][4]
   // exchange block each)
-  constexpr int NT = (G * UB + 15) / 16, BCH = GCH / 2, CW = UB / 4;
+  // BC = 32-k blocks of W_hh a wave keeps resident (bf16-split form): 1, 2 or 4, sized by the host to ceil(H/32 / NW)
+  constexpr int NT = (G * UB + 15) / 16, BCH = BC, CW = UB / 4;
+  // granule hand-off (XCD-local mode) only where its buffers fit the register budget of two workgroups per CU: the
+  // 4-block form (LSTM-512 on 4 waves) keeps the flag words instead
+  constexpr bool GRAN = B3 && BC <= 2;
   static_assert(UB % 4 == 0 && CW <= NW, "cell waves");
   // partial tiles, double-buffered by step parity: in XCD-local mode no barrier separates a step's readers (cell
   // threads) from the next step's writers
@@ -343,21 +347,24 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       for (int e = 0; e < 4; ++e) acc[nt][e] = 0.f;
     float4 av[B3 ? 1 : GCH];
     float4 aw[B3 ? BCH : 1][2];
-    // next step's x projection (hoisted above the hand-off: its latency hides behind the wait)
+    // next step's x projection: requested BEHIND this step's hand-off loads (loads return in order: requested first it
+    // would put its HBM latency in front of them); it is not needed before the next step's cell update
     float xn[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) xn[g] = 0.f;
-    if (cthr && s + 1 < L) {
-      const int cn = d == 0 ? s + 1 : L - 2 - s;
-      const float* xr = a.xp + ((long)cn * a.B + cb) * ldx + (long)d * G * H + cun;
+    auto request_xn = [&]() {
+      if (cthr && s + 1 < L) {
+        const int cn = d == 0 ? s + 1 : L - 2 - s;
+        const float* xr = a.xp + ((long)cn * a.B + cb) * ldx + (long)d * G * H + cun;
 #pragma unroll
-      for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
-    }
+        for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
+      }
+    };
     const bool gl = local;              // protocol of THIS step's operands (the mode may change below, at s == 1)
-    if (s > 0 && gl && B3) {
+    if (s > 0 && gl && GRAN) {
       // XCD-local, bf16-split: granules (file header).  Block c+1 is requested before block c is consumed; a block whose
       // tags are not all the awaited ones is re-loaded until they are.
-      if constexpr (B3) {
+      if constexpr (GRAN) {
         const unsigned want_hi = ((unsigned)s & 0xFFFFu) << 16;
         const unsigned gbase = (unsigned)(((long)2 * par_floats * 4) + ((long)((s - 1) & 1) * par_floats + base_floats) * 8);
         auto offs = [&](int c, unsigned& oa, unsigned& ob) {
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
           }
         if (!ok && lane == 0) s_fail = 1;
       }
+      request_xn();
     } else if (s > 0) {
       if (gl) {          // XCD-local, f32 MFMA form: flag words; every wave waits for the producers of its own slice
         if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
@@ -419,6 +427,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
             const long quad = 4 * (g0 + c) + q;
             av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
           }
+        request_xn();
 #pragma unroll
         for (int c = 0; c < GCH; ++c)
           if (g0 + c < g1) {
@@ -433,6 +442,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
             aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
             aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
           }
+        request_xn();
 #pragma unroll
         for (int c = 0; c < BCH; ++c)
           if (kb0 + c < kb1) {
@@ -443,6 +453,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
           }
       }
     }
+    if (s == 0) request_xn();
     store_partials<NT>(red, wave, lane, acc);
     __syncthreads();
     if (s_fail) {                                          // a wave's poll ran out (XCD-local mode): leave together
@@ -480,14 +491,14 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       hprev = hnew;
       // exchange block [CW*chunk + jq][16][4] of parity s&1, before anything else
       const long xe = (long)(s & 1) * par_floats + base_floats + (((long)CW * chunk + jq) * MB + ci) * 4 + jj;
-      if (local && B3) {                // (granule mode: stored below, for EVERY row)
+      if (local && GRAN) {              // (granule mode: stored below, for EVERY row)
       } else if (local) {
         __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain: stays in the XCD's L2
       } else {
         __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
       }
     }
-    if (local && B3) {
+    if (local && GRAN) {
       // granule {hi, mid, lo, tag = s + 1}: one 8-byte plain store per (row, unit), nothing else to signal.  EVERY row
       // slot is written every step -- rows beyond the batch and finished items as zeros -- because a consumer accepts a
       // block only once all its tags are the awaited ones
@@ -1231,13 +1242,13 @@ double plan_launch(KernelT kernel, int block, Geom& geo, int& grid, hipStream_t 
   return -1.0;
 }
 
-template <int G, int NW, bool B3, int UB>
+template <int G, int NW, bool B3, int UB, int BC>
 int launch_fwd_persist(const RnnFwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
   int grid = 0;
-  const double cus = plan_launch(ft_rnn_fwd_persist_kernel<G, NW, B3, UB>, NW * 64, geo, grid, stream);
+  const double cus = plan_launch(ft_rnn_fwd_persist_kernel<G, NW, B3, UB, BC>, NW * 64, geo, grid, stream);
   if (cus < 0.0) return -1;
   (void)hipMemsetAsync(p.cnt, 0, p.total_bytes, stream);
-  hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3, UB>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb,
+  hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3, UB, BC>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb,
                      p.cnt, ft_rnn_fault_word(), (unsigned)p.xb_bytes);
   admitted_launch_done(cus, stream);
   return ft_check_launch("rnn_fwd_persistent");
@@ -1252,14 +1263,15 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   int NW = ngroups > 16 ? 8 : 4;
   // 4-wave workgroups for the widest layer too (H = 512: each wave keeps 4 of the 16 k-blocks): 256-thread workgroups
   // run two per CU, so the 64 workgroups of a (direction, batch group) group fit ONE XCD and hand over through its L2
-  if (NW == 8 && G == 4 && H % 32 == 0 && ft_cdiv(H / 32, 4) <= GCH / 2 && env_int("FT_RNN_FWD_NW4", 1)) NW = 4;
+  if (NW == 8 && G == 4 && H % 32 == 0 && ft_cdiv(H / 32, 4) <= 4 && env_int("FT_RNN_FWD_NW4", 1)) NW = 4;
   if (ft_cdiv(ngroups, NW) > GCH) return -1;
-  const bool b3 = H % 32 == 0 && ft_cdiv(H / 32, NW) <= GCH / 2 && env_int("FT_RNN_B3", 1);   // bf16 pipe (exact split)
+  const int bpw = H % 32 == 0 ? ft_cdiv(H / 32, NW) : 99;                 // 32-k blocks per wave in the split form
+  const bool b3 = bpw <= 4 && env_int("FT_RNN_B3", 1);                    // matmul on the bf16 pipe (exact split)
   // 16 units per workgroup where 8 would need more than the 32 workgroups per group one XCD can host (H = 512): the
   // group then fits one XCD and runs XCD-local -- but the kernel needs 256 registers per lane AND spills 57 dwords,
   // measured 5.65 us/step against 3.77 for the 8-unit form on the agent-scope protocol (lab/rnn_step_us.py): off by
   // default (FT_RNN_FWD_UB16=1 enables it), kept for the day the register diet succeeds
-  const bool wide = b3 && NW == 8 && G == 4 && H / 8 > 32 && H % 16 == 0 && env_int("FT_RNN_FWD_UB16", 0);
+  const bool wide = b3 && NW == 8 && G == 4 && H / 8 > 32 && H % 16 == 0 && bpw <= 2 && env_int("FT_RNN_FWD_UB16", 0);
   Geom geo;
   geo.nchunks = H / (wide ? 16 : 8);
   geo.nbg = ft_cdiv(B, MB);
@@ -1272,12 +1284,16 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.xcd_off = 0;
   geo.local_ok = 0;
   a.s = 0;
-  if (wide) return launch_fwd_persist<G, 8, true, 16>(a, geo, p, stream);
-  if (b3)
-    return NW == 8 ? launch_fwd_persist<G, 8, true, 8>(a, geo, p, stream)
-                   : launch_fwd_persist<G, 4, true, 8>(a, geo, p, stream);
-  return NW == 8 ? launch_fwd_persist<G, 8, false, 8>(a, geo, p, stream)
-                 : launch_fwd_persist<G, 4, false, 8>(a, geo, p, stream);
+  if (wide) return launch_fwd_persist<G, 8, true, 16, 2>(a, geo, p, stream);
+  if (b3) {
+    if (NW == 8) return bpw <= 1 ? launch_fwd_persist<G, 8, true, 8, 1>(a, geo, p, stream)
+                                 : launch_fwd_persist<G, 8, true, 8, 2>(a, geo, p, stream);     // (NW = 8: bpw <= 2)
+    if (bpw <= 1) return launch_fwd_persist<G, 4, true, 8, 1>(a, geo, p, stream);
+    if (bpw <= 2) return launch_fwd_persist<G, 4, true, 8, 2>(a, geo, p, stream);
+    return launch_fwd_persist<G, 4, true, 8, 4>(a, geo, p, stream);
+  }
+  return NW == 8 ? launch_fwd_persist<G, 8, false, 8, 1>(a, geo, p, stream)
+                 : launch_fwd_persist<G, 4, false, 8, 1>(a, geo, p, stream);
 }
 
 template <int G, int NW, int GW, bool B3>
