@@ -105,6 +105,7 @@ struct Geom {
   int xcd_off;                         // group-aligned placement: physical XCD of logical slot 0
   unsigned max_spins;                  // bound of every arrival poll (ft_rnn_set_max_spins; tests force timeouts with it)
   int local_ok;                        // groups are XCD-slot aligned: the XCD-local hand-off may be used if placement agrees
+  int gran;                            // XCD-local hand-off by granules where the kernel has them (FT_RNN_GRANULES=0: flag words)
 };
 
 // sticky per-device fault word (one 128-B line of its own): set by any workgroup whose poll ran out, cleared only by
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       }
     };
     const bool gl = local;              // protocol of THIS step's operands (the mode may change below, at s == 1)
-    if (s > 0 && gl && GRAN) {
+    if (s > 0 && gl && GRAN && geo.gran) {
       // XCD-local, bf16-split: granules (file header).  Block c+1 is requested before block c is consumed; a block whose
       // tags are not all the awaited ones is re-loaded until they are.
       if constexpr (GRAN) {
@@ -491,14 +492,14 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       hprev = hnew;
       // exchange block [CW*chunk + jq][16][4] of parity s&1, before anything else
       const long xe = (long)(s & 1) * par_floats + base_floats + (((long)CW * chunk + jq) * MB + ci) * 4 + jj;
-      if (local && GRAN) {              // (granule mode: stored below, for EVERY row)
+      if (local && GRAN && geo.gran) {  // (granule mode: stored below, for EVERY row)
       } else if (local) {
         __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // plain: stays in the XCD's L2
       } else {
         __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
       }
     }
-    if (local && GRAN) {
+    if (local && GRAN && geo.gran) {
       // granule {hi, mid, lo, tag = s + 1}: one 8-byte plain store per (row, unit), nothing else to signal.  EVERY row
       // slot is written every step -- rows beyond the batch and finished items as zeros -- because a consumer accepts a
       // block only once all its tags are the awaited ones
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
   const int gpw = (ngroups + NW - 1) / NW;
   const int g0 = wave * gpw, g1 = min(ngroups, g0 + gpw);
   constexpr int BW = GW / 2;                        // B3: 32-k blocks per wave
+  constexpr bool GRAN = B3 && BW <= 4;              // granule hand-off in XCD-local mode (see the forward kernel)
   const int nblk = K / 32;
   const int bpw = (nblk + NW - 1) / NW;
   const int kb0 = wave * bpw, kb1 = min(nblk, kb0 + bpw);
@@ -651,61 +653,98 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
     for (int e = 0; e < 4; ++e) acc[0][e] = 0.f;
     float4 av[B3 ? 1 : GW];
     float4 aw[B3 ? BW : 1][2];
-    if (s > 0) {
-      if (local) {       // every wave waits for the producers of its own slice; a timeout is acted on at the next barrier
-        if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
-      } else {
-        if (wave == 0) {
-          const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
-          if (s == 1 && ok && geo.local_ok) {
-            const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
-            if (lane == 0) s_local = same;
-          }
-          if (lane == 0) s_ok = ok;
-        }
-        __syncthreads();
-        if (!s_ok) {
-          if (tid == 0) atomicExch(fault, 1u);
-          return;
-        }
-        if (s == 1) {
-          local = s_local != 0;
-          if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);    // statistics: groups per mode
-        }
-      }
-      const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
-      if constexpr (!B3) {
-#pragma unroll
-        for (int c = 0; c < GW; ++c)
-          if (g0 + c < g1) {
-            const long quad = 4 * (g0 + c) + q;
-            av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
-          }
-      } else {
-#pragma unroll
-        for (int c = 0; c < BW; ++c)
-          if (kb0 + c < kb1) {
-            const long quad = 8 * (kb0 + c) + 2 * q;
-            aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
-            aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
-          }
-      }
-    }
     float ngv[4], ndo, ncc, nprev;
-    request(s + 1, ngv, ndo, ncc, nprev);
-    if (s > 0) {
-      if constexpr (!B3) {
-#pragma unroll
-        for (int c = 0; c < GW; ++c)
-          if (g0 + c < g1) mfma4(av[c], bv[c], acc[0]);
-      } else {
+    const bool gl = local;              // protocol of THIS step's operands (the mode may change below, at s == 1)
+    if (s > 0 && gl && GRAN && geo.gran) {
+      // XCD-local, bf16-split: granules (see the forward kernel / file header)
+      if constexpr (GRAN) {
+        const unsigned want_hi = ((unsigned)s & 0xFFFFu) << 16;
+        const unsigned gbase = (unsigned)(((long)2 * par_floats * 4) + ((long)((s - 1) & 1) * par_floats + base_floats) * 8);
+        auto offs = [&](int c, unsigned& oa, unsigned& ob) {
+          const long quad = 8 * (kb0 + c) + 2 * q;
+          oa = gbase + (unsigned)((quad * MB + l15) * 4 * 8);
+          ob = gbase + (unsigned)(((quad + 1) * MB + l15) * 4 * 8);
+        };
+        Gran gr[2];
+        unsigned oa, ob;
+        if (kb0 < kb1) {
+          offs(0, oa, ob);
+          gran_load(gr[0], rs, oa, ob);
+        }
+        bool ok = true;
 #pragma unroll
         for (int c = 0; c < BW; ++c)
           if (kb0 + c < kb1) {
+            if (c + 1 < BW && kb0 + c + 1 < kb1) {
+              unsigned na, nb;
+              offs(c + 1, na, nb);
+              gran_load(gr[(c + 1) & 1], rs, na, nb);
+            }
+            offs(c, oa, ob);
+            ok = gran_wait(gr[c & 1], rs, oa, ob, want_hi, geo.max_spins) && ok;
             bf16x8 a3[3];
-            split8(aw[c][0], aw[c][1], a3[0], a3[1], a3[2]);
+            gran_unpack(gr[c & 1], a3);
             mfma6(a3, bw[c], acc[0]);
           }
+        if (!ok && lane == 0) s_fail = 1;
+      }
+      request(s + 1, ngv, ndo, ncc, nprev);
+    } else {
+      if (s > 0) {
+        if (gl) {        // XCD-local, flag words: every wave waits for the producers of its own slice
+          if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
+        } else {
+          if (wave == 0) {
+            const bool ok = wait_arrivals(mycnt, (unsigned)s, nprod, lane, geo.max_spins);
+            if (s == 1 && ok && geo.local_ok) {
+              const bool same = same_xcd(myxcc, geo.nchunks, my_xcc, lane);
+              if (lane == 0) s_local = same;
+            }
+            if (lane == 0) s_ok = ok;
+          }
+          __syncthreads();
+          if (!s_ok) {
+            if (tid == 0) atomicExch(fault, 1u);
+            return;
+          }
+          if (s == 1) {
+            local = s_local != 0;
+            if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);    // statistics: groups per mode
+          }
+        }
+        const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
+        if constexpr (!B3) {
+#pragma unroll
+          for (int c = 0; c < GW; ++c)
+            if (g0 + c < g1) {
+              const long quad = 4 * (g0 + c) + q;
+              av[c] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+            }
+        } else {
+#pragma unroll
+          for (int c = 0; c < BW; ++c)
+            if (kb0 + c < kb1) {
+              const long quad = 8 * (kb0 + c) + 2 * q;
+              aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+              aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
+            }
+        }
+      }
+      request(s + 1, ngv, ndo, ncc, nprev);
+      if (s > 0) {
+        if constexpr (!B3) {
+#pragma unroll
+          for (int c = 0; c < GW; ++c)
+            if (g0 + c < g1) mfma4(av[c], bv[c], acc[0]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < BW; ++c)
+            if (kb0 + c < kb1) {
+              bf16x8 a3[3];
+              split8(aw[c][0], aw[c][1], a3[0], a3[1], a3[2]);
+              mfma6(a3, bw[c], acc[0]);
+            }
+        }
       }
     }
     store_partials<1>(red, wave, lane, acc);
@@ -749,12 +788,25 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float v = (G == 3 && g == 2) ? dgh2 : dgx[g];
-        float* q = xw + (((long)(g * H + u0) / 4 + j4) * MB + ci) * 4 + jj;
-        if (local) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long xe = (((long)(g * H + u0) / 4 + j4) * MB + ci) * 4 + jj;
+        if (local && GRAN && geo.gran) continue;           // (granule mode: stored below, for every row)
+        if (local) __hip_atomic_store(xw + xe, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else __hip_atomic_store(xw + xe, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (geo.sig_per_wave) {
+    if (local && GRAN && geo.gran) {
+      if (sthr) {        // every (row, k) slot, every step: rows beyond the batch / finished items as zeros
+        unsigned long long* gp = reinterpret_cast<unsigned long long*>(xb + 2 * par_floats) + (long)(s & 1) * par_floats +
+                                 base_floats;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float v = cthr ? ((G == 3 && g == 2) ? dgh2 : dgx[g]) : 0.f;
+          const long xe = (((long)(g * H + u0) / 4 + j4) * MB + ci) * 4 + jj;
+          __hip_atomic_store(gp + xe, gran_make(v, (unsigned)(s + 1) & 0xFFFFu), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    } else if (geo.sig_per_wave) {
       if (sthr) {                                          // waves 0..3, wave-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -1236,6 +1288,7 @@ double plan_launch(KernelT kernel, int block, Geom& geo, int& grid, hipStream_t 
     grid = cand[i].grid;
     geo.xcd_off = cand[i].xcd_off;
     geo.local_ok = cand[i].aligned && env_int("FT_RNN_LOCAL", 1);
+    geo.gran = env_int("FT_RNN_GRANULES", 1);
     return d;
   }
   ++g_n_refused;
@@ -1283,6 +1336,7 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   geo.xcd_off = 0;
   geo.local_ok = 0;
+  geo.gran = 0;
   a.s = 0;
   if (wide) return launch_fwd_persist<G, 8, true, 16, 2>(a, geo, p, stream);
   if (b3) {
@@ -1362,6 +1416,7 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.max_spins = g_max_spins;
   geo.xcd_off = 0;
   geo.local_ok = 0;
+  geo.gran = 0;
   a.s = 0;
   {
     const int rc = bwd_persistent_rs<G>(a, geo, ws, ws_bytes, stream);
