@@ -116,7 +116,7 @@ def dominant_kernel_roofline(bank_ms):
     return out
 
 
-def family_rooflines(recs, steps, batch, step_ms):
+def family_rooflines(recs, steps, batch, step_ms, lr_iso_ms=None):
     """Per-step totals of the recurrence launches (time-dominant family) and of the LengthRegulator expansion."""
     B = int(batch['x'].shape[0])
     trunk = {'ms': 0.0, 'flop': 0.0, 'dep_steps': 0, 'launches': 0}
@@ -146,9 +146,12 @@ def family_rooflines(recs, steps, batch, step_ms):
                     'achieved': round(tf, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(tf / F32_MFMA_PEAK_TFLOPS, 4)})
     if lr_ms > 0:
-        tbs = lr_bytes / (lr_ms * 1e-3) / 1e12
+        ms = lr_iso_ms if lr_iso_ms else lr_ms / steps
+        tbs = lr_bytes / steps / (ms * 1e-3) / 1e12
         out.append({'family': 'LengthRegulator expand (ft_lr_expand_kernel)', 'bound': 'hbm',
-                    'ms_per_step': round(lr_ms / steps, 4), 'bytes_per_launch': lr_bytes / steps,
+                    'launch_ms': round(ms, 4), 'timing': '50 launches back to back between one event pair' if lr_iso_ms
+                    else 'event pair around the in-step launch', 'in_step_event_pair_ms': round(lr_ms / steps, 4),
+                    'bytes_per_launch': lr_bytes / steps,
                     'achieved': round(tbs * 1e3, 1), 'peak': HBM_PEAK_TBS * 1e3, 'unit': 'GB/s',
                     'frac': round(tbs / HBM_PEAK_TBS, 4)})
     return out
@@ -176,10 +179,27 @@ def install_family_probes(probes, batch):
     def lr(a, k):
         x, cum, Tm = a[0], a[1], a[2]
         Bq, Tx, C = x.shape
+        probes.lr_args = (x, cum, Tm)            # for the back-to-back timing below (the operands of the last step)
         # algorithmic bytes: one 4*C-byte row read per valid token + one written per output frame (B x Tm)
         return {'bytes': 4.0 * C * (float(batch['x_len'].sum()) + Bq * Tm)}
 
     probes.wrap('lr_expand', lr)
+
+
+def lr_back_to_back_ms(hip_mod, args, n=50):
+    """An event pair around ONE 12-us launch mostly measures the events; n launches back to back between one pair give the
+    kernel's own time (+ the ~1.5 us dependent-launch boundary).  The output tensor is re-allocated per call by the
+    wrapper (caching allocator: no device work)."""
+    x, cum, Tm = args
+    for _ in range(3):
+        hip_mod.lr_expand(x, cum, Tm)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        hip_mod.lr_expand(x, cum, Tm)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
 
 
 def cpu_baseline(model_cfg, train_cfg, budget_s, threads):
@@ -327,7 +347,8 @@ def main():
                 one_step()
             torch.cuda.synchronize()
             fp.remove()
-            fam = family_rooflines(fp.results(), args.family_steps, batch, elapsed / args.steps * 1e3)
+            lr_iso = lr_back_to_back_ms(_hip, fp.lr_args) if getattr(fp, 'lr_args', None) else None
+            fam = family_rooflines(fp.results(), args.family_steps, batch, elapsed / args.steps * 1e3, lr_iso)
         flag = torch.tensor([ok], device=device)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)

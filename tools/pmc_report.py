@@ -45,6 +45,8 @@ def main():
     ap.add_argument('--kernel')
     ap.add_argument('--grid-wgs', type=int)
     ap.add_argument('--shape')
+    ap.add_argument('--pick', default='0/1', help='i/n: of the matching launches take every n-th starting at i (a step may '
+                    'hold several launches of one kernel and grid: the conv-bank forward is the first of two)')
     args = ap.parse_args()
     data = load(args.root)
     want = [k for k in args.kernels.split(',') if k]
@@ -71,9 +73,11 @@ def main():
         if key is None:
             raise SystemExit('no kernel with both FETCH_SIZE and WRITE_SIZE matches')
         d = data[key]
-        fe, wr = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']), sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
+        pi, pn = (int(v) for v in args.pick.split('/'))
+        fsel, wsel = d['FETCH_SIZE'][pi::pn], d['WRITE_SIZE'][pi::pn]
+        fe, wr = sum(fsel) / len(fsel), sum(wsel) / len(wsel)
         rec = {'kernel': key[0], 'grid_workgroups': key[1], 'shape': [int(v) for v in args.shape.split(',')],
-               'launches': len(d['FETCH_SIZE']), 'fetch_size_kib': fe, 'write_size_kib': wr,
+               'launches': len(fsel), 'picked': args.pick, 'fetch_size_kib': fe, 'write_size_kib': wr,
                'traffic_bytes_per_launch': (2 * fe + wr) * 1024,
                'method': 'separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; FETCH_SIZE x 2 (gfx950, wide '
                          'coalesced reads) + WRITE_SIZE, KiB -> bytes'}
