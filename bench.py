@@ -134,7 +134,7 @@ def family_rooflines(recs, steps, batch, step_ms, lr_iso_ms=None):
         acc['launches'] += 1
     out = []
     for tag, acc in (('trunk (prenet GRU-256, LSTM-512, postnet GRU-128; the step\'s critical stream)', trunk),
-                     ('predictors (3 x GRU, side stream, overlapped)', side)):
+                     ('predictors (3 x GRU, side stream, overlapped; the event pairs include the device-side waits behind the trunk\'s launches)', side)):
         if not acc['launches']:
             continue
         ms, tf = acc['ms'] / steps, acc['flop'] / steps / (acc['ms'] / steps * 1e-3) / 1e12
