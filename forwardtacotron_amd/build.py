@@ -18,6 +18,8 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-I', INCLUDE, '-I', CSRC]
+# per-file additions (each explained in the file's own header comments)
+EXTRA = {'ft_gemm_b3.hip': ['-fno-slp-vectorize']}
 
 
 def _sources():
@@ -39,7 +41,7 @@ def _compile(src, force, hdr_m):
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) > max(os.path.getmtime(sp), hdr_m)):
         return obj, False, ''
-    r = subprocess.run([HIPCC] + FLAGS + ['-c', sp, '-o', obj], capture_output=True, text=True)
+    r = subprocess.run([HIPCC] + FLAGS + EXTRA.get(src, []) + ['-c', sp, '-o', obj], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed on {src}:\n{r.stdout}\n{r.stderr}')
     return obj, True, r.stderr

@@ -27,6 +27,7 @@ constexpr int RS = 104;          // LDS row stride in bf16 elements: 3 planes x 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, bool ok) {
   const float4 v = *reinterpret_cast<const float4*>(ok ? p : safe);
@@ -43,10 +44,17 @@ __device__ __forceinline__ unsigned rn_pack(float a, float b) {
   const bf16x2v p = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(unsigned, p);
 }
+// the packed value is made opaque (an empty asm: no instruction) before it is taken apart: with the conversion visible,
+// "hi << 16" becomes a SECOND v_cvt_pk_bf16_f32 of (a, 0) -- one more VALU per pair and level.  [Real inline-asm
+// instructions are not an option: sched_group_barrier does not count them as VALU and the MFMA interleave falls apart.]
+// The file is built with -fno-slp-vectorize: the SLP pass packs the two subtractions into a v_pk_add_f32, which costs
+// more than two v_sub_f32 beside MFMAs.
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
   hi = rn_pack(a, b);
+  asm("" : "+v"(hi));
   const float a1 = a - __uint_as_float(hi << 16), b1 = b - __uint_as_float(hi & 0xFFFF0000u);
   mid = rn_pack(a1, b1);
+  asm("" : "+v"(mid));
   const float a2 = a1 - __uint_as_float(mid << 16), b2 = b1 - __uint_as_float(mid & 0xFFFF0000u);
   lo = rn_pack(a2, b2);
 }
@@ -72,6 +80,82 @@ __device__ __forceinline__ void store_rn(unsigned short* row, const float4& v) {
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   bf16x4 r = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
   *reinterpret_cast<bf16x4*>(row) = r;
+}
+
+// epilogue shared by the two NT kernels: bias / ReLU / BatchNorm statistics / scale-shift / accumulate, same accumulator
+// layout as ft_gemm_rows_kernel.  `smem` = the (now idle) LDS tiles, >= 4 KB.
+template <int TM, int TN>
+__device__ __forceinline__ void rows_b3_epilogue(const FtGemmTask& T, float* TC, f32x16 (&acc)[TM][TN], unsigned short* smem,
+                                                 int m0, int n0, int tM, int tN, int tid, int mtile) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* ebias = T.bias;
+  const float* escale = T.scale;
+  const float* eshift = T.shift;
+  const bool erelu = T.relu != 0, eacc = T.accumulate != 0;
+  const long ldc = T.ldc, cbst = T.cmap.bstride, ctst = T.cmap.tstride;
+  const int cTlog = T.cmap.Tlog;
+  double* const stat = (TM == 2 && TN == 2) ? T.stat : nullptr;
+  const int sTlog = T.amap.Tlog, sTv = T.stat_tvalid;
+  const int srow0 = m0 + wm * 32 * TM + 4 * half;          // first row of this lane; t = row % Tlog tracked without divisions
+  const int stb = stat ? srow0 % sTlog : 0;
+  const bool ssmall = sTlog < 32 * TM;
+  double* sred = reinterpret_cast<double*>(smem);          // [wm 2][128 columns][2] doubles = 4 KB of the (now idle) tiles
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * 32 * TN + 32 * j + l31;
+    const bool col_ok = col < tN;
+    const float bv = (ebias && col_ok) ? ebias[col] : 0.f;
+    const float sc = (escale && col_ok) ? escale[col] : 1.f;
+    const float sh = (escale && col_ok) ? eshift[col] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row >= tM || !col_ok) continue;
+        long crow = row;
+        if (cbst != 0) {
+          const int cb = row / cTlog;
+          crow = (long)cb * cbst + (long)(row - cb * cTlog) * ctst;
+        }
+        float* cp = TC + crow * ldc + col;
+        float v = acc[i][j][e] + bv;
+        if (erelu) v = fmaxf(v, 0.f);
+        if (stat) {
+          int tt = stb + (row - srow0);                    // < 2 * Tlog unless Tlog is tiny
+          if (ssmall) tt %= sTlog;
+          else if (tt >= sTlog) tt -= sTlog;
+          if (tt < sTv) {
+            s0 += (double)v;
+            s1 += (double)v * (double)v;
+          }
+        }
+        if (escale) v = v * sc + sh;
+        if (eacc) v += *cp;
+        *cp = v;
+      }
+    }
+    if (stat) {            // lanes l31 and l31 + 32 hold the two row halves of a column: fold, then across the wm waves
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (half == 0) {
+        double* q = sred + ((wm * 128) + wn * 32 * TN + 32 * j + l31) * 2;
+        q[0] = s0;
+        q[1] = s1;
+      }
+    }
+  }
+  if (stat) {
+    __syncthreads();
+    if (tid < 128 && n0 + tid < tN) {
+      double* o = stat + ((long)mtile * T.stat_ld + T.stat_col0 + n0 + tid) * 2;
+      o[0] = sred[tid * 2] + sred[(128 + tid) * 2];
+      o[1] = sred[tid * 2 + 1] + sred[(128 + tid) * 2 + 1];
+    }
+  }
 }
 
 template <int TM, int TN, int NP>
@@ -236,73 +320,311 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
     }
   }
 
-  // epilogue: identical to ft_gemm_rows_kernel (same accumulator layout), plus the optional BatchNorm statistics
-  const float* ebias = T.bias;
-  const float* escale = T.scale;
-  const float* eshift = T.shift;
-  const bool erelu = T.relu != 0, eacc = T.accumulate != 0;
-  const long ldc = T.ldc, cbst = T.cmap.bstride, ctst = T.cmap.tstride;
-  const int cTlog = T.cmap.Tlog;
-  double* const stat = (TM == 2 && TN == 2) ? T.stat : nullptr;
-  const int sTlog = T.amap.Tlog, sTv = T.stat_tvalid;
-  const int srow0 = m0 + wm * 32 * TM + 4 * half;          // first row of this lane; t = row % Tlog tracked without divisions
-  const int stb = stat ? srow0 % sTlog : 0;
-  const bool ssmall = sTlog < 32 * TM;
-  double* sred = reinterpret_cast<double*>(smem);          // [wm 2][128 columns][2] doubles = 4 KB of the (now idle) tiles
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn * 32 * TN + 32 * j + l31;
-    const bool col_ok = col < tN;
-    const float bv = (ebias && col_ok) ? ebias[col] : 0.f;
-    const float sc = (escale && col_ok) ? escale[col] : 1.f;
-    const float sh = (escale && col_ok) ? eshift[col] : 0.f;
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (row >= tM || !col_ok) continue;
-        long crow = row;
-        if (cbst != 0) {
-          const int cb = row / cTlog;
-          crow = (long)cb * cbst + (long)(row - cb * cTlog) * ctst;
-        }
-        float* cp = TC + crow * ldc + col;
-        float v = acc[i][j][e] + bv;
-        if (erelu) v = fmaxf(v, 0.f);
-        if (stat) {
-          int tt = stb + (row - srow0);                    // < 2 * Tlog unless Tlog is tiny
-          if (ssmall) tt %= sTlog;
-          else if (tt >= sTlog) tt -= sTlog;
-          if (tt < sTv) {
-            s0 += (double)v;
-            s1 += (double)v * (double)v;
-          }
-        }
-        if (escale) v = v * sc + sh;
-        if (eacc) v += *cp;
-        *cp = v;
-      }
-    }
-    if (stat) {            // lanes l31 and l31 + 32 hold the two row halves of a column: fold, then across the wm waves
-      s0 += __shfl_xor(s0, 32, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      if (half == 0) {
-        double* q = sred + ((wm * 128) + wn * 32 * TN + 32 * j + l31) * 2;
-        q[0] = s0;
-        q[1] = s1;
-      }
-    }
+  rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The 128x128 NT kernel, software-pipelined ("b3p").  The two-barrier loop above tops out where the guide's "step-3
+// structure" does (35 % of the bf16 pipe: MFMA busy 46-53 % in profiles/r02_pmc_report.txt): a wave alternates between
+// an MFMA phase and a staging phase (split VALU + ds_write + two barriers) and the two workgroups of a CU drift into
+// phase with each other.  Here a stage is 16 k deep and LDS holds TWO of them (2 x 24 KB, still two workgroups per CU),
+// so one iteration = [issue the global loads of stage c+2] [fragments of stage c] [24 MFMAs, with the split + ds_write of
+// stage c+1 issued in their shadow -- one scheduling region, no branch inside] [ONE barrier].  Plain VGPR loads stay in
+// flight across __syncthreads() (only LDS-DMA would force its vmcnt(0)), so a load has two iterations to land.
+// Layout: row = [plane][16 k] bf16, 96 B (48 B for NP = 1) -- an odd multiple of 16/32 B, which spreads 16 consecutive
+// lanes' ds_read_b128 / ds_write_b128 over all 64 banks with no padding column.  A thread stages 8 k of one A row and one
+// B row per stage (two float4 each, k0 + 4h and k0 + 8 + 4h so the wave's two loads are 32 contiguous bytes per row);
+// the k ORDER inside a stage is therefore permuted, identically for A and B, which a dot product does not see.
+template <int NP>
+__global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch batch) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, SK = 16;
+  constexpr int RW = NP == 3 ? 48 : 24;            // row stride, bf16 elements
+  constexpr int BUF = (BM + BN) * RW;
+  // XCD-aware tile walk: workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD has its own L2.  Within
+  // every z slice (= task or batch instance: slices differ in work per tile, so each is spread over all XCDs) the
+  // workgroups that share an XCD take a CONTIGUOUS range of the slice's (row tile, column tile) space, column tile
+  // fastest: the workgroups resident on one XCD at a time share their A row tiles (and stream the same k window of B)
+  // through that L2 instead of every XCD fetching every operand tile again (lab/gemm_b3p_lab.hip).  Bijective for any
+  // grid: `xcd` only labels the workgroups of the slice that share an XCD.
+  int bx, by;
+  const int bz = blockIdx.z;
+  {
+    const int gy = gridDim.y;
+    const int nwg = gridDim.x * gy;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, q = nwg >> 3, r = nwg & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    bx = w / gy;
+    by = w - bx * gy;
   }
-  if (stat) {
+  const bool zbatch = batch.t[0].nz > 1;
+  const FtGemmTask& T = batch.t[zbatch ? 0 : bz];
+  const float* TA = T.A;
+  const float* TB = T.B;
+  float* TC = T.C;
+  if (zbatch) {
+    const int z0 = bz / T.nz1, z1 = bz - z0 * T.nz1;
+    TA += z0 * T.sA0 + z1 * T.sA1;
+    TB += z0 * T.sB0 + z1 * T.sB1;
+    TC += z0 * T.sC0 + z1 * T.sC1;
+  }
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * BUF];
+
+  const int m0 = bx * BM, n0 = by * BN;
+  if (m0 >= T.M || n0 >= T.N) return;
+  const int tid = threadIdx.x;
+  const int h = tid & 1, rr = tid >> 1;            // k half of the stage, tile row (A and B)
+
+  const int tM = T.M, tN = T.N;
+  const int nchain = batch.chain > 1 ? batch.chain : 1;
+  // Operands are fetched with buffer loads: the descriptor base is the tile's first row at the stage's (tap shift, k0) --
+  // all scalar -- and a lane's voffset is constant per task.  A row outside the time window / the tile's M, N range or a
+  // k beyond K gets an out-of-range voffset and the hardware returns zeros: no exec-masked branch per load (what hipcc
+  // makes of "ok ? *p : 0", one basic block per load) and no select on the loaded value.
+  constexpr unsigned OOB = 0x80000000u, NREC = 0x7fffffffu;
+  int tK, taps, Tvalid, shift0, sstep, kch, a_t;
+  long lda, btap, atst;
+  const float* a_base;
+  const float* b_base;
+  bool a_ok;
+  unsigned a_voff, vb, vbad0, vbad1;                 // bit 31 of a voffset = out of range = the load returns zeros
+  unsigned va0, va1, vb0, vb1;                       // the voffsets of the stage under the cursor (two 16-B loads per row)
+  bool ktail;                                        // K is not a multiple of the stage depth: the last chunk is masked
+  const float* tapA;                                 // descriptor bases per (task, tap); the k position of a stage goes
+  const float* tapB;                                 // into soffset
+  int l_task = 0, l_tap = 0, l_kc = 0;             // loader cursor
+  // per-tap state: everything a stage's loads need except k0 -- kept out of the per-stage path, which runs between a
+  // barrier and the next stage's requests with the matrix pipe draining
+  auto mask_tail = [&]() {
+    va0 |= vbad0;
+    va1 |= vbad1;
+    vb0 |= vbad0;
+    vb1 |= vbad1;
+  };
+  auto set_tap = [&]() {
+    const int shift = shift0 + l_tap * sstep;
+    const int ts = a_t + shift;
+    va0 = (a_ok & (ts >= 0) & (ts < Tvalid)) ? a_voff : OOB;
+    va1 = va0 + 32u;
+    vb0 = vb;
+    vb1 = vb + 32u;
+    if (ktail && kch == 1) mask_tail();
+    tapA = a_base + (long)shift * atst * lda;
+    tapB = b_base + (long)l_tap * btap;
+  };
+  auto setup = [&](const FtGemmTask& S, const float* SA, const float* SB) {
+    tK = S.K;
+    taps = S.taps;
+    lda = S.lda;
+    btap = S.b_tap_stride;
+    Tvalid = S.amap.Tvalid;
+    shift0 = S.amap.shift0;
+    sstep = S.amap.shift_step;
+    atst = S.amap.tstride;
+    kch = (tK + SK - 1) / SK;
+    const int Tlog = S.amap.Tlog;
+    const long abst = S.amap.bstride;
+    const int bt0 = m0 / Tlog;
+    long row0 = (long)bt0 * abst + (long)(m0 - bt0 * Tlog) * atst;            // the tile's lowest physical row (scalar):
+    if (m0 - bt0 * Tlog + BM > Tlog && (long)(bt0 + 1) * abst < row0)         // its first one, or -- time-major layouts --
+      row0 = (long)(bt0 + 1) * abst;                                          // the head of the next batch item
+    a_base = SA + row0 * lda;
+    const int m = m0 + rr;
+    a_ok = m < tM;
+    const int b = m / Tlog;
+    a_t = m - b * Tlog;
+    a_voff = (unsigned)((((long)b * abst + (long)a_t * atst) - row0) * lda * 4) + 16u * h;
+    b_base = SB + (long)n0 * S.ldb;
+    vb = n0 + rr < tN ? (unsigned)((long)rr * S.ldb * 4) + 16u * h : OOB;
+    const int kl = (kch - 1) * SK;                   // only the last k chunk of a tap can reach past K
+    ktail = tK % SK != 0;
+    vbad0 = kl + 4 * h < tK ? 0u : OOB;
+    vbad1 = kl + 8 + 4 * h < tK ? 0u : OOB;
+    set_tap();
+  };
+  setup(T, TA, TB);
+  int nch = 0;
+  for (int i = 0; i < nchain; ++i) nch += batch.t[i].taps * ((batch.t[i].K + SK - 1) / SK);
+  if (nchain == 1) nch = taps * kch;
+
+  struct Regs { u32x4 a0, a1, b0, b1; };
+  // issue the four loads of the stage under the cursor.  No branch in here (the loads, the split of the older register
+  // set and the MFMAs share one scheduling region, and the compiler's vmcnt counting stops at a branch).  A row outside
+  // the tap's time window / the tile's M, N range or a k beyond K has bit 31 set in its voffset: out of range for the
+  // descriptor, the hardware returns zeros -- no exec-masked branch per load (what hipcc makes of "ok ? *p : 0") and no
+  // select on the loaded value.
+  auto load_stage = [&](Regs& R) {
+    // the descriptors are rebuilt from readfirstlane'd halves: a loop-carried descriptor is not provably uniform to
+    // hipcc, which would wrap every load in a waterfall loop
+    auto uniform = [](const float* q) {
+      const unsigned long long u = (unsigned long long)q;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+      return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    };
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(uniform(tapA), 0, NREC, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(uniform(tapB), 0, NREC, 0x00020000);
+    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(l_kc * SK * 4);
+    R.a0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va0, soff, 0);
+    R.a1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va1, soff, 0);
+    R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0, soff, 0);
+    R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb1, soff, 0);
+    __builtin_amdgcn_sched_barrier(0);              // keep the requests at the top of the iteration (hipcc sinks them to
+  };                                                // the bottom otherwise: zero prefetch distance)
+  auto advance = [&]() {
+    if (++l_kc == kch) {
+      l_kc = 0;
+      if (++l_tap == taps) {
+        l_tap = 0;
+        if (++l_task < nchain) setup(batch.t[l_task], batch.t[l_task].A, batch.t[l_task].B);
+      } else {
+        set_tap();
+      }
+    } else if (ktail && l_kc == kch - 1) {
+      mask_tail();
+    }
+  };
+  // 8 floats -> NP pieces of 8 bf16, one ds_write_b128 each
+  auto put8 = [&](unsigned short* row, const u32x4& uu, const u32x4& vv) {
+    const float4 u = __builtin_bit_cast(float4, uu), v = __builtin_bit_cast(float4, vv);
+    if constexpr (NP == 1) {
+      const uint4 w = make_uint4(rn_pack(u.x, u.y), rn_pack(u.z, u.w), rn_pack(v.x, v.y), rn_pack(v.z, v.w));
+      *reinterpret_cast<uint4*>(row) = w;
+    } else {
+      unsigned hi[4], mid[4], lo[4];
+      split_pair(u.x, u.y, hi[0], mid[0], lo[0]);
+      split_pair(u.z, u.w, hi[1], mid[1], lo[1]);
+      split_pair(v.x, v.y, hi[2], mid[2], lo[2]);
+      split_pair(v.z, v.w, hi[3], mid[3], lo[3]);
+      *reinterpret_cast<uint4*>(row) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      *reinterpret_cast<uint4*>(row + 16) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+      *reinterpret_cast<uint4*>(row + 32) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+  };
+  auto store_stage = [&](const Regs& R, unsigned short* buf) {
+    put8(buf + rr * RW + 8 * h, R.a0, R.a1);
+    put8(buf + (BM + rr) * RW + 8 * h, R.b0, R.b1);
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int aoff = (wm * 64 + l31) * RW + 8 * half;
+  const int boff = (BM + wn * 64 + l31) * RW + 8 * half;
+  // the split of the next stage goes into the shadow of this stage's MFMAs: 1 MFMA (8 passes) : a few VALU
+  auto interleave = [&]() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NP, 0);  // the fragment reads
+#pragma unroll
+    for (int i = 0; i < TM * TN * (NP == 3 ? 6 : 1); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 5 : 8, 0);   // VALU
+    }
+  };
+  // TWO fragment sets: the fragments of stage c+1 are read during the MFMAs of stage c (from the buffer the barrier at
+  // the end of iteration c-1 published), so no MFMA waits for an LDS read behind a barrier.  Reads come BEFORE the next
+  // stage's ds_writes in program order: the compiler cannot prove the two LDS buffers distinct and would otherwise keep
+  // them behind the whole split + write block.
+  bf16x8 fa[TM][NP], fb[TN][NP], ga[TM][NP], gb[TN][NP];
+  auto read_into = [&](bf16x8 (&xa)[TM][NP], bf16x8 (&xb)[TN][NP], const unsigned short* buf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) xa[i][pl] = *reinterpret_cast<const bf16x8*>(buf + aoff + 32 * i * RW + 16 * pl);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) xb[j][pl] = *reinterpret_cast<const bf16x8*>(buf + boff + 32 * j * RW + 16 * pl);
+  };
+  // term-major order: consecutive MFMAs go to different accumulators; each accumulator receives its six terms small-first
+  auto mfma_on = [&](bf16x8 (&xa)[TM][NP], bf16x8 (&xb)[TN][NP]) {
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int term = 0; term < (NP == 3 ? 6 : 1); ++term)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int pa = NP == 3 ? PA_[term] : 0, pb = NP == 3 ? PB_[term] : 0;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i][pa], xb[j][pb], acc[i][j], 0, 0, 0);
+        }
+  };
+
+  unsigned short* const buf0 = smem;
+  unsigned short* const buf1 = smem + BUF;
+  Regs R0, R1;
+  load_stage(R0);
+  advance();
+  if (nch > 1) {
+    load_stage(R1);
+    advance();
+  }
+  store_stage(R0, buf0);                             // stage 0
+  __syncthreads();
+  if (nch > 2) {
+    load_stage(R0);                                  // stage 2
+    advance();
+  }
+  read_into(fa, fb, buf0);
+  if (nch > 1) store_stage(R1, buf1);                // stage 1
+  __syncthreads();
+  // iteration c (even): fragments of stage c in (fa, fb), stage c+1 in buf1, stage c+2 in R0 (in flight), cursor at c+3.
+  //   first half : request c+3 -> R1 | read c+1 -> (ga, gb) | split + write c+2 -> buf0 | MFMA c     | barrier
+  //   second half: request c+4 -> R0 | read c+2 -> (fa, fb) | split + write c+3 -> buf1 | MFMA c+1   | barrier
+  int c = 0;
+  for (; c + 4 < nch; c += 2) {
+    load_stage(R1);
+    read_into(ga, gb, buf1);
+    store_stage(R0, buf0);
+    mfma_on(fa, fb);
+    interleave();
     __syncthreads();
-    if (tid < 128 && n0 + tid < tN) {
-      double* o = stat + ((long)blockIdx.x * T.stat_ld + T.stat_col0 + n0 + tid) * 2;
-      o[0] = sred[tid * 2] + sred[(128 + tid) * 2];
-      o[1] = sred[tid * 2 + 1] + sred[(128 + tid) * 2 + 1];
-    }
+    advance();
+    load_stage(R0);
+    read_into(fa, fb, buf0);
+    store_stage(R1, buf1);
+    mfma_on(ga, gb);
+    interleave();
+    __syncthreads();
+    advance();
   }
+  const int left = nch - c;                          // 1 .. 4 stages, same state as at the top of an iteration
+  if (left == 4) {
+    load_stage(R1);                                  // c+3
+    read_into(ga, gb, buf1);
+    store_stage(R0, buf0);                           // c+2
+    mfma_on(fa, fb);
+    __syncthreads();
+    read_into(fa, fb, buf0);
+    store_stage(R1, buf1);                           // c+3
+    mfma_on(ga, gb);
+    __syncthreads();
+    read_into(ga, gb, buf1);
+    mfma_on(fa, fb);
+    mfma_on(ga, gb);
+  } else if (left == 3) {
+    read_into(ga, gb, buf1);
+    store_stage(R0, buf0);                           // c+2
+    mfma_on(fa, fb);
+    __syncthreads();
+    read_into(fa, fb, buf0);
+    mfma_on(ga, gb);
+    mfma_on(fa, fb);
+  } else if (left == 2) {
+    read_into(ga, gb, buf1);
+    mfma_on(fa, fb);
+    mfma_on(ga, gb);
+  } else {
+    mfma_on(fa, fb);
+  }
+  __syncthreads();                                   // the epilogue's statistics scratch aliases the tiles
+  rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, bx);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -537,7 +859,23 @@ int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per
 // NT, FAST (16-B aligned operands, K % 4 == 0) launches only; grid / tile choice made by ft_launch_gemm_rows
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream) {
   const bool bf16 = ft_gemm_precision() == 1;
-  if (big) {
+  static const bool pipelined = [] {                 // FT_GEMM_PIPE=0: the two-barrier 128x128 kernel (A/B knob)
+    const char* e = getenv("FT_GEMM_PIPE");
+    return !(e && e[0] == '0');
+  }();
+  // the pipelined kernel addresses a tile's rows with 32-bit byte offsets from the tile's first row (buffer loads)
+  bool span_ok = true;
+  const int ntask = batch.chain > 1 ? batch.chain : (int)grid.z;
+  for (int i = 0; i < (batch.t[0].nz > 1 ? 1 : ntask) && i < FT_MAX_TASKS; ++i) {
+    const FtGemmTask& t = batch.t[i];
+    const long tl = t.amap.Tlog, ts = t.amap.tstride, bs = t.amap.bstride;
+    const long rows = (tl < 128 ? tl : 128) * ts + (128 / tl + 2) * bs + tl * ts;     // bound on a tile's physical row span
+    span_ok = span_ok && ts >= 0 && bs >= 0 && rows * t.lda * 4 < (1L << 31) && 128L * t.ldb * 4 < (1L << 31);
+  }
+  if (big && pipelined && span_ok) {
+    if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1>), grid, dim3(256), 0, stream, batch);
+    else hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3>), grid, dim3(256), 0, stream, batch);
+  } else if (big) {
     if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 1>), grid, dim3(256), 0, stream, batch);
     else hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 3>), grid, dim3(256), 0, stream, batch);
   } else {

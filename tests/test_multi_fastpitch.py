@@ -107,9 +107,18 @@ def test_gpu_train_step_through_trainer(Z):
     ts = TrainStep(m, lr=float(Z['lr']), train_cfg=TRAIN_CFG_MULTI)
     out = ts.step({k: v.clone().cuda() for k, v in sub(Z, 'batch/').items()})
     assert abs(float(out['loss']) - float(Z['loss/total'])) < 2e-5
+    grads = sub(Z, 'grad/')
+    # per-parameter gradients first: a wrong norm alone does not say WHICH gradient is off
+    names = [n for n, _ in m.named_parameters()]
+    bad = []
+    for n, p in zip(names, ts.flat.params):
+        if n in grads:
+            d = maxdiff(p.grad.cpu(), grads[n])
+            if not d < 3e-5 + 3e-5 * float(abs(grads[n]).max()):
+                bad.append((n, d, float(abs(grads[n]).max())))
+    assert not bad, bad
     assert abs(float(out['grad_norm']) - float(Z['grad_norm'])) < 1e-4 * max(1.0, float(Z['grad_norm']))
     sd = m.state_dict()
-    grads = sub(Z, 'grad/')
     for k, v in sub(Z, 'sd_after/').items():
         if v.dtype.is_floating_point and not k.endswith('.pe'):
             live = grads[k].abs() > 1e-6
