@@ -49,12 +49,20 @@ class GradSink:
         self.held = set()               # indices queued in `pending`: claimed, not yet issued (the all-reduce must wait)
         self.main = None
         self.used = set()               # streams gradient writes were issued on this step
+        # operands of side-stream launches, kept REFERENCED until the step has joined the side stream.  record_stream only
+        # keeps their memory from being recycled; it does not keep autograd from ADDING INTO them: a gradient tensor handed
+        # to two consumers (LayerNorm's dx for branch and residual, AddBackward's grad for both addends) is accumulated
+        # in place -- on the emitting stream -- as soon as it is uniquely owned, i.e. right after the conv / linear node
+        # whose weight gradient is still reading it on the side stream has returned (seen as rare wrong conv2 weight
+        # gradients in MultiFastPitch's predictors).  A live reference makes autograd add out of place instead.
+        self.keep = []
 
     def begin_step(self):
         self.written.clear()
         self.pending.clear()
         self.held.clear()
         self.used.clear()
+        self.keep.clear()
         self.main = torch.cuda.current_stream() if torch.cuda.is_available() else None   # the step's critical stream
 
 
@@ -111,6 +119,7 @@ def _side_launch(compute, views, deps, idxs) -> None:
         t.record_stream(side)
     with torch.cuda.stream(side):
         compute(views)
+    _SINK.keep.append(deps)
     for i in idxs:
         _sink_done(i)
 
@@ -143,6 +152,7 @@ def flush_end(pend) -> None:
             for t in deps:
                 t.record_stream(side)
             compute(views)
+            sink.keep.append(deps)
     for _, _, _, idxs, _ in pend:
         for i in idxs:
             sink.held.discard(i)

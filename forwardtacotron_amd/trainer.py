@@ -170,6 +170,7 @@ class TrainStep:
         for st in self.sink.used:               # e.g. the predictors' side stream: its backward wrote gradients too
             if st != cur and st != self.wgrad_stream:
                 cur.wait_stream(st)
+        self.sink.keep.clear()                  # joined: nothing reads the side launches' operands any more
         self.reducer.finish()
         self.optimizer_step()
         out = {k: v.detach() for k, v in L.items()}

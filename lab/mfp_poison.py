@@ -23,8 +23,7 @@ def run(poison):
     ts = TrainStep(m, lr=float(Z['lr']), train_cfg=TRAIN_CFG_MULTI)
     out = ts.step({k: v.clone().cuda() for k, v in sub(Z, 'batch/').items()})
     torch.cuda.synchronize()
-    names = [n for n, _ in m.named_parameters()]
-    grads = {n: p.grad.detach().clone().cpu() for n, p in zip(names, ts.flat.params)}
+    grads = {n: p.grad.detach().clone().cpu() for n, p in m.named_parameters()}
     return float(out['loss']), float(out['grad_norm']), grads
 
 

@@ -109,9 +109,8 @@ def test_gpu_train_step_through_trainer(Z):
     assert abs(float(out['loss']) - float(Z['loss/total'])) < 2e-5
     grads = sub(Z, 'grad/')
     # per-parameter gradients first: a wrong norm alone does not say WHICH gradient is off
-    names = [n for n, _ in m.named_parameters()]
     bad = []
-    for n, p in zip(names, ts.flat.params):
+    for n, p in m.named_parameters():           # p.grad is the parameter's view into the flat gradient buffer
         if n in grads:
             d = maxdiff(p.grad.cpu(), grads[n])
             if not d < 3e-5 + 3e-5 * float(abs(grads[n]).max()):
