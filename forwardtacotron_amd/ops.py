@@ -7,6 +7,7 @@ the autograd graph.
 """
 from typing import List, Optional
 
+import os
 import torch
 from torch.autograd import Function
 
@@ -165,16 +166,20 @@ def flush_deferred() -> None:
     flush_end(flush_begin())
 
 
-def _emit(w: torch.Tensor, compute, deps=(), heavy: bool = True):
+def _emit(w: torch.Tensor, compute, deps=(), heavy=True):
     """Produces the gradient of parameter `w`: compute(out) must overwrite `out` (same shape as w).
     Without a sink: returns a fresh tensor (autograd accumulates it).  With a sink: writes the flat-buffer
-    view (on the side stream when `heavy`) and returns None."""
+    view (on the side stream when `heavy`) and returns None.  heavy='light': a small reduction (bias gradient) that nothing
+    on the step's critical stream waits for -- it joins the queued side-stream launches of a deferring sink (22 column
+    sums + finalizes = 0.4 ms of the ForwardTacotron step's main stream) and stays inline otherwise."""
     ent = _sink_view(w)
     if ent is None:
         out = torch.empty_like(w)
         compute(out)
         return out
     idx, view = ent
+    if heavy == 'light':
+        heavy = _SINK.defer and bool(deps) and os.environ.get('FT_BIAS_GRADS_SIDE', '1') == '1'
     side = _SINK.stream if heavy else None
     if side is not None and deps and deps[0].numel() // deps[0].shape[-1] <= _SINK.inline_rows:
         side = None                     # short (token-side) operands: see GradSink.inline_rows
@@ -280,7 +285,7 @@ class LinearFn(Function):
         dw = _emit(w, wgrad, (dy, x))
         db = None
         if b is not None:
-            db = _emit(b, lambda out: H.colsum_raw(dy.data_ptr(), out_f, out, rows, out_f), heavy=False)
+            db = _emit(b, lambda out: H.colsum_raw(dy.data_ptr(), out_f, out, rows, out_f), (dy,), heavy='light')
         return dx, dw, db, None
 
 
@@ -435,8 +440,8 @@ class HighwayFn(Function):
         dw1 = _emit(w1, lambda out: H.linear_bwd_weight_raw(p, 2 * C, x.data_ptr(), C, out, rows, C, C), (d12, x))
         dw2 = _emit(w2, lambda out: H.linear_bwd_weight_raw(p + C * _F4, 2 * C, x.data_ptr(), C, out, rows, C, C),
                     (d12, x))
-        db1 = _emit(b1, lambda out: H.colsum_raw(p, 2 * C, out, rows, C), heavy=False)
-        db2 = _emit(b2, lambda out: H.colsum_raw(p + C * _F4, 2 * C, out, rows, C), heavy=False)
+        db1 = _emit(b1, lambda out: H.colsum_raw(p, 2 * C, out, rows, C), (d12,), heavy='light')
+        db2 = _emit(b2, lambda out: H.colsum_raw(p + C * _F4, 2 * C, out, rows, C), (d12,), heavy='light')
         return dx, dw1, db1, dw2, db2
 
 
