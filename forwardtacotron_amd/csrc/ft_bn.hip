@@ -16,6 +16,47 @@ __device__ __forceinline__ int tvalid_of(int c, int Tbuf, int group) {
   return (group > 0 && (((c / group) + 1) & 1)) ? Tbuf - 1 : Tbuf;
 }
 
+// ---- BatchNorm apply fused with MaxPool1d(2,1,1)[:T] (CBHG bank: common_layers.py:100-105) -----------------------------
+// z[t] = (y[t] - mean) * rstd * gamma + beta is never stored: the forward writes out[t] = max(z[t-1], z[t]) straight
+// from y, and the backward recomputes the three z rows a pooling gradient needs with the SAME expression (so the
+// argmax decisions are bit-identical to the forward's):
+//   dz[t] = dout[t] * [t == 0 or z[t] > z[t-1]]  +  dout[t+1] * [t+1 < T and not z[t+1] > z[t]]
+// (torch sends a window's gradient to its FIRST maximal element: after the ReLU a bank row is full of equal zeros).
+struct BnAff4 { float4 mu, rs, ga, be; };
+__device__ __forceinline__ float4 bn_z4(const float4& v, const BnAff4& a) {
+  float4 o;
+  o.x = (v.x - a.mu.x) * a.rs.x * a.ga.x + a.be.x;
+  o.y = (v.y - a.mu.y) * a.rs.y * a.ga.y + a.be.y;
+  o.z = (v.z - a.mu.z) * a.rs.z * a.ga.z + a.be.z;
+  o.w = (v.w - a.mu.w) * a.rs.w * a.ga.w + a.be.w;
+  return o;
+}
+// dz of row (b, t), t < Tout, 4 channels; yrow = &y[(b*Tbuf + t)*C + c], drow = &dout[(b*Tout + t)*C + c]; vt = y[t]
+__device__ __forceinline__ float4 pool_grad4(const float* __restrict__ yrow, const float* __restrict__ drow,
+                                             const float4& vt, int t, int Tout, int C, const BnAff4& a) {
+  const float4 z = bn_z4(vt, a);
+  const float4 d0 = *reinterpret_cast<const float4*>(drow);
+  float4 g;
+  if (t == 0) {
+    g = d0;
+  } else {
+    const float4 p = bn_z4(*reinterpret_cast<const float4*>(yrow - C), a);
+    g.x = z.x > p.x ? d0.x : 0.f;
+    g.y = z.y > p.y ? d0.y : 0.f;
+    g.z = z.z > p.z ? d0.z : 0.f;
+    g.w = z.w > p.w ? d0.w : 0.f;
+  }
+  if (t + 1 < Tout) {
+    const float4 n = bn_z4(*reinterpret_cast<const float4*>(yrow + C), a);
+    const float4 d1 = *reinterpret_cast<const float4*>(drow + C);
+    g.x += !(n.x > z.x) ? d1.x : 0.f;
+    g.y += !(n.y > z.y) ? d1.y : 0.f;
+    g.z += !(n.z > z.z) ? d1.z : 0.f;
+    g.w += !(n.w > z.w) ? d1.w : 0.f;
+  }
+  return g;
+}
+
 // mode 0: (sum y, sum y^2) over rows t < tvalid(c) of y[B,Tbuf,C]
 // mode 1: (sum dout, sum dout*xhat), dout[B,Tout,C] (zero for t >= Tout), xhat from y, mean, rstd
 // mode 2: (sum x, 0) over all rows of x[rows, ldx] (bias gradients); Tbuf = rows, B = 1
@@ -132,7 +173,10 @@ __global__ __launch_bounds__(256) void ft_col_partial4_kernel(const float* __res
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int B, int Tbuf, int Tout,
                                                               int C, int group, int rows_per_chunk,
-                                                              double* __restrict__ partial) {
+                                                              double* __restrict__ partial,
+                                                              const float* __restrict__ gamma = nullptr,
+                                                              const float* __restrict__ beta = nullptr) {
+  // MODE 2 = MODE 1 with dout being the gradient of the POOLED output: dz is recomputed per element (pool_grad4)
   __shared__ double red[2][16][65];
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + cq * 4;
@@ -144,9 +188,16 @@ __global__ __launch_bounds__(256) void ft_col_partial4_kernel(const float* __res
   if (c < C) {
     const int tv = tvalid_of(c, Tbuf, group);
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu;
-    if (MODE == 1) {
+    BnAff4 aff;
+    if (MODE >= 1) {
       mu = *reinterpret_cast<const float4*>(mean + c);
       rs = *reinterpret_cast<const float4*>(rstd + c);
+    }
+    if (MODE == 2) {
+      aff.mu = mu;
+      aff.rs = rs;
+      aff.ga = *reinterpret_cast<const float4*>(gamma + c);
+      aff.be = *reinterpret_cast<const float4*>(beta + c);
     }
     int bb[4], tt[4];
 #pragma unroll
@@ -165,6 +216,9 @@ __global__ __launch_bounds__(256) void ft_col_partial4_kernel(const float* __res
         v[u] = ok[u] ? *reinterpret_cast<const float4*>(y + rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == 1)
           g[u] = ok[u] ? *reinterpret_cast<const float4*>(dout + ((long)bb[u] * Tout + tt[u]) * C + c)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 2)
+          g[u] = ok[u] ? pool_grad4(y + rr * C + c, dout + ((long)bb[u] * Tout + tt[u]) * C + c, v[u], tt[u], Tout, C, aff)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
@@ -350,6 +404,36 @@ __global__ __launch_bounds__(256) void ft_bn_apply4_kernel(const float4* __restr
   out[idx] = o;
 }
 
+// out[b,t] = max(z[b,t-1], z[b,t]) (z[-1] = -inf), z never stored
+__global__ __launch_bounds__(256) void ft_bn_apply_pool4_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float4* __restrict__ out,
+                                                                long total4, int Tbuf, int Tout, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int C4 = C / 4;
+  const int c = (int)(idx % C4) * 4;
+  const long row = idx / C4;
+  const int b = (int)(row / Tout), t = (int)(row - (long)b * Tout);
+  BnAff4 a;
+  a.mu = *reinterpret_cast<const float4*>(mean + c);
+  a.rs = *reinterpret_cast<const float4*>(rstd + c);
+  a.ga = *reinterpret_cast<const float4*>(gamma + c);
+  a.be = *reinterpret_cast<const float4*>(beta + c);
+  const float* yrow = y + ((long)b * Tbuf + t) * C + c;
+  float4 z = bn_z4(*reinterpret_cast<const float4*>(yrow), a);
+  if (t > 0) {
+    const float4 p = bn_z4(*reinterpret_cast<const float4*>(yrow - C), a);
+    z.x = z.x > p.x ? z.x : p.x;
+    z.y = z.y > p.y ? z.y : p.y;
+    z.z = z.z > p.z ? z.z : p.z;
+    z.w = z.w > p.w ? z.w : p.w;
+  }
+  out[idx] = z;
+}
+
+template <bool POOL>
 __global__ __launch_bounds__(256) void ft_bn_bwd_apply4_kernel(const float4* __restrict__ dout, const float4* __restrict__ y,
                                                                const float4* __restrict__ mean,
                                                                const float4* __restrict__ rstd,
@@ -357,7 +441,8 @@ __global__ __launch_bounds__(256) void ft_bn_bwd_apply4_kernel(const float4* __r
                                                                const float4* __restrict__ dgamma,
                                                                const float4* __restrict__ dbeta, float4* __restrict__ dy,
                                                                long total4, int B, int Tbuf, int Tout, int C4, int group,
-                                                               int relu) {
+                                                               int relu, const float4* __restrict__ beta = nullptr) {
+  // POOL: dout is the gradient of the pooled output, the BatchNorm output's gradient is recomputed (pool_grad4)
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total4) return;
   const int c = (int)(idx % C4);
@@ -367,9 +452,19 @@ __global__ __launch_bounds__(256) void ft_bn_bwd_apply4_kernel(const float4* __r
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
   if (t < tv) {
     const float4 v = y[idx];
-    const float4 g = t < Tout ? dout[((long)b * Tout + t) * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float inv_n = 1.0f / ((float)B * (float)tv);
     const float4 mu = mean[c], rs = rstd[c], ga = gamma[c], dg = dgamma[c], db = dbeta[c];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < Tout) {
+      if constexpr (POOL) {
+        BnAff4 a;
+        a.mu = mu; a.rs = rs; a.ga = ga; a.be = beta[c];
+        g = pool_grad4(reinterpret_cast<const float*>(y + idx), reinterpret_cast<const float*>(dout + ((long)b * Tout + t) * C4 + c),
+                       v, t, Tout, 4 * C4, a);
+      } else {
+        g = dout[((long)b * Tout + t) * C4 + c];
+      }
+    }
+    const float inv_n = 1.0f / ((float)B * (float)tv);
 #define FT_BN_BWD1(f)                                                                \
   {                                                                                  \
     const float xh = (v.f - mu.f) * rs.f;                                            \
@@ -516,14 +611,55 @@ int ft_bn_bwd(const float* dout, const float* y, const float* gamma, const float
                      p.nchunks, C, dbeta, dgamma, 1.0f, 0);
   long total = (long)B * Tbuf * C;
   if (C % 4 == 0 && (group == 0 || group % 4 == 0) && all16(dout, y, save_mean, save_rstd, gamma, dgamma, dbeta, dy))
-    hipLaunchKernelGGL(ft_bn_bwd_apply4_kernel, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, s, (const float4*)dout,
+    hipLaunchKernelGGL(ft_bn_bwd_apply4_kernel<false>, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, s, (const float4*)dout,
                        (const float4*)y, (const float4*)save_mean, (const float4*)save_rstd, (const float4*)gamma,
                        (const float4*)dgamma, (const float4*)dbeta, (float4*)dy, total / 4, B, Tbuf, Tout, C / 4, group,
-                       relu);
+                       relu, nullptr);
   else
     hipLaunchKernelGGL(ft_bn_bwd_apply_kernel, dim3(ft_cdiv(total, 256)), dim3(256), 0, s, dout, y, save_mean, save_rstd,
                        gamma, dgamma, dbeta, dy, B, Tbuf, Tout, C, group, relu);
   return ft_check_launch("bn_bwd");
+}
+
+// CBHG bank (training): finalize the statistics partials, then out[B,Tout,C] = MaxPool1d(2,1,1)(BatchNorm(y))[:Tout] in
+// one pass over y -- the normalised tensor is never written.  16-B path only (C % 4 == 0, group % 4 == 0, aligned).
+int ft_bn_pool_from_partials(const double* partial, int nchunks, const float* y, const float* gamma, const float* beta,
+                             float* out, float* running_mean, float* running_var, long* num_batches_tracked,
+                             float* save_mean, float* save_rstd, int B, int Tbuf, int Tout, int C, int group,
+                             float momentum, float eps, void* stream) {
+  FT_REQUIRE(B > 0 && Tbuf > 0 && C > 0 && Tout > 0 && Tout <= Tbuf && nchunks >= 1, "bn_pool_from_partials: bad dims");
+  FT_REQUIRE(C % 4 == 0 && (group == 0 || group % 4 == 0) && all16(y, save_mean, save_rstd, gamma, beta, out),
+             "bn_pool_from_partials: needs C %% 4 == 0 and 16-byte aligned buffers");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ft_bn_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, partial, nchunks, B, Tbuf, C, group,
+                     momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_rstd);
+  const long total = (long)B * Tout * C;
+  hipLaunchKernelGGL(ft_bn_apply_pool4_kernel, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, s, y, save_mean, save_rstd,
+                     gamma, beta, (float4*)out, total / 4, Tbuf, Tout, C);
+  return ft_check_launch("bn_pool_from_partials");
+}
+
+// backward of the pair above: dout [B,Tout,C] = gradient of the POOLED output; dy [B,Tbuf,C], dgamma, dbeta as ft_bn_bwd
+int ft_bn_pool_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                   const float* save_rstd, float* dy, float* dgamma, float* dbeta, int B, int Tbuf, int Tout, int C,
+                   int group, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(B > 0 && Tbuf > 0 && C > 0 && Tout > 0 && Tout <= Tbuf, "bn_pool_bwd: bad dims");
+  FT_REQUIRE(workspace && workspace_bytes >= ft_bn_workspace(B, Tbuf, C), "bn_pool_bwd: workspace too small");
+  FT_REQUIRE(C % 4 == 0 && (group == 0 || group % 4 == 0) &&
+                 all16(dout, y, save_mean, save_rstd, gamma, beta, dgamma, dbeta, dy),
+             "bn_pool_bwd: needs C %% 4 == 0 and 16-byte aligned buffers");
+  hipStream_t s = (hipStream_t)stream;
+  ChunkPlan p = plan_chunks((long)B * Tbuf, C);
+  hipLaunchKernelGGL(ft_col_partial4_kernel<2>, dim3(ft_cdiv(C, 64), p.nchunks), dim3(256), 0, s, y, dout, save_mean,
+                     save_rstd, B, Tbuf, Tout, C, group, p.rows_per_chunk, (double*)workspace, gamma, beta);
+  hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
+                     p.nchunks, C, dbeta, dgamma, 1.0f, 0);
+  const long total = (long)B * Tbuf * C;
+  hipLaunchKernelGGL(ft_bn_bwd_apply4_kernel<true>, dim3(ft_cdiv(total / 4, 256)), dim3(256), 0, s, (const float4*)dout,
+                     (const float4*)y, (const float4*)save_mean, (const float4*)save_rstd, (const float4*)gamma,
+                     (const float4*)dgamma, (const float4*)dbeta, (float4*)dy, total / 4, B, Tbuf, Tout, C / 4, group, relu,
+                     (const float4*)beta);
+  return ft_check_launch("bn_pool_bwd");
 }
 
 int ft_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

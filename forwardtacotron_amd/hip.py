@@ -514,6 +514,40 @@ def bn_bwd(dout: torch.Tensor, y: torch.Tensor, gamma, mean, rstd, group: int, r
     return dy, dgamma, dbeta
 
 
+def bn_pool_fusable(y: torch.Tensor, group: int) -> bool:
+    """the fused BatchNorm + MaxPool kernels take the 16-byte path only"""
+    return y.shape[-1] % 4 == 0 and group % 4 == 0 and y.data_ptr() % 16 == 0
+
+
+def bn_pool_from_partials(part: torch.Tensor, nchunks: int, y: torch.Tensor, gamma, beta, running_mean, running_var,
+                          Tout: int, group: int = 0, momentum: float = None, eps: float = None):
+    """finalize the statistics partials + MaxPool1d(2,1,1)(bn(y))[:Tout] in one pass over y (the normalised tensor is
+    never stored): -> (out [B,Tout,C], save_mean, save_rstd)"""
+    B, Tbuf, C = y.shape
+    out = torch.empty(B, Tout, C, device=y.device, dtype=y.dtype)
+    mean = torch.empty(C, device=y.device, dtype=y.dtype)
+    rstd = torch.empty(C, device=y.device, dtype=y.dtype)
+    _lib.call('ft_bn_pool_from_partials', _p(part), nchunks, _p(y), _p(gamma), _p(beta), _p(out), _p(running_mean),
+              _p(running_var), None, _p(mean), _p(rstd), B, Tbuf, Tout, C, group,
+              BN_MOMENTUM if momentum is None else momentum, BN_EPS if eps is None else eps, _stream())
+    return out, mean, rstd
+
+
+def bn_pool_bwd(dout: torch.Tensor, y: torch.Tensor, gamma, beta, mean, rstd, group: int, relu: bool):
+    """backward of bn_pool_from_partials: dout = gradient of the pooled output -> (dy [B,Tbuf,C], dgamma, dbeta)"""
+    _chk(dout, 'dout'); _chk(y, 'y')
+    B, Tbuf, C = y.shape
+    Tout = dout.shape[1]
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, device=y.device, dtype=y.dtype)
+    dbeta = torch.empty(C, device=y.device, dtype=y.dtype)
+    nbytes = _lib.query('ft_bn_workspace', B, Tbuf, C)
+    ws = workspace(nbytes, y.device)
+    _lib.call('ft_bn_pool_bwd', _p(dout), _p(y), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dy), _p(dgamma), _p(dbeta),
+              B, Tbuf, Tout, C, group, int(relu), _p(ws), ws.numel(), _stream())
+    return dy, dgamma, dbeta
+
+
 def bn_fold_eval(gamma, beta, running_mean, running_var, eps: float = BN_EPS):
     C = gamma.numel()
     scale = torch.empty(C, device=gamma.device, dtype=gamma.dtype)

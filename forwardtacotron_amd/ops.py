@@ -362,9 +362,17 @@ class ConvBankFn(Function):
         C = ws[0].shape[0]
         wp_all = H.bank_packs(ws, False)
         ybank, part, nch = H.conv_bank_fwd_stats(x, wp_all, K, C, relu=True)
-        z, mean, rstd = H.bn_train_from_partials(part, nch, ybank, gamma, beta, running_mean, running_var, Tout=T,
-                                                 group=C)
-        out = H.maxpool2_fwd(z)
+        # BatchNorm apply + MaxPool in one pass over the bank buffer: the normalised tensor z is neither written nor kept
+        # (postnet: 220 MB), the backward recomputes the pooling decisions from ybank (FT_BN_POOL_FUSED=0: three passes)
+        ctx.fused = H.bn_pool_fusable(ybank, C) and os.environ.get('FT_BN_POOL_FUSED', '1') == '1'
+        if ctx.fused:
+            out, mean, rstd = H.bn_pool_from_partials(part, nch, ybank, gamma, beta, running_mean, running_var, Tout=T,
+                                                      group=C)
+            z = beta
+        else:
+            z, mean, rstd = H.bn_train_from_partials(part, nch, ybank, gamma, beta, running_mean, running_var, Tout=T,
+                                                     group=C)
+            out = H.maxpool2_fwd(z)
         ctx.save_for_backward(x, wp_all, ybank, z, gamma, mean, rstd, *params)
         ctx.K, ctx.C = K, C
         return out
@@ -376,8 +384,11 @@ class ConvBankFn(Function):
         K, C = ctx.K, ctx.C
         ws, gs, bs = params[:K], params[K:2 * K], params[2 * K:3 * K]
         B, T, Cin = x.shape
-        dz = H.maxpool2_bwd(_c(dout), z)
-        dy, dgamma, dbeta = H.bn_bwd(dz, ybank, gamma, mean, rstd, group=C, relu=True)
+        if ctx.fused:                     # (the `z` slot holds beta)
+            dy, dgamma, dbeta = H.bn_pool_bwd(_c(dout), ybank, gamma, z, mean, rstd, group=C, relu=True)
+        else:
+            dz = H.maxpool2_bwd(_c(dout), z)
+            dy, dgamma, dbeta = H.bn_bwd(dz, ybank, gamma, mean, rstd, group=C, relu=True)
         dx = H.conv_bank_bwd_data(dy, wp_all, K, C, Cin, T, ws=ws) if ctx.needs_input_grad[0] else None
         if C % 128 == 0:        # all members' weight gradients in one launch
             dws = _emit_multi(ws, lambda outs: H.conv_bank_bwd_weight(dy, x, outs, C), (dy, x))

@@ -205,6 +205,21 @@ int ft_bn_train_from_partials(const double* partial, int nchunks, const float* y
                               const float* residual, float* out, float* running_mean, float* running_var,
                               long* num_batches_tracked, float* save_mean, float* save_rstd, int B, int Tbuf, int Tout,
                               int C, int group, float momentum, float eps, void* stream);
+/* CBHG conv bank, training mode (common_layers.py:100-105): BatchNorm apply fused with MaxPool1d(2,1,1)[:Tout].
+ * ft_bn_pool_from_partials: finalize the partials as ft_bn_train_from_partials, then out[B,Tout,C][t] =
+ *   max(z[t-1], z[t]) with z = bn(y) recomputed on the fly -- z is never written.
+ * ft_bn_pool_bwd: dout[B,Tout,C] is the gradient of the POOLED output; the BatchNorm output's gradient (torch's
+ *   max_pool rule: a window's gradient goes to its first maximal element) is recomputed from y in both passes
+ *   (statistics and apply), so neither z nor dz ever exists in memory.  dy / dgamma / dbeta as ft_bn_bwd.
+ * Both need C % 4 == 0, group % 4 == 0 and 16-byte aligned buffers (FT_ERR otherwise: callers fall back to
+ * ft_bn_train_from_partials + ft_maxpool2_fwd / ft_maxpool2_bwd + ft_bn_bwd). */
+int ft_bn_pool_from_partials(const double* partial, int nchunks, const float* y, const float* gamma, const float* beta,
+                             float* out, float* running_mean, float* running_var, long* num_batches_tracked,
+                             float* save_mean, float* save_rstd, int B, int Tbuf, int Tout, int C, int group,
+                             float momentum, float eps, void* stream);
+int ft_bn_pool_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                   const float* save_rstd, float* dy, float* dgamma, float* dbeta, int B, int Tbuf, int Tout, int C,
+                   int group, int relu, void* workspace, size_t workspace_bytes, void* stream);
 int ft_bn_train_fwd(const float* y, const float* gamma, const float* beta, const float* residual, float* out,
                     float* running_mean, float* running_var, long* num_batches_tracked, float* save_mean,
                     float* save_rstd, int B, int Tbuf, int Tout, int C, int group, float momentum, float eps,

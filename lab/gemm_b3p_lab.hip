@@ -378,11 +378,20 @@ int main() {
   for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
   hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
-  run<0, 2, 2, 2, 2, 2>("full", A, B, C, M, N, K);
-  run<0, 2, 2, 2, 2, 2>("full (again)", A, B, C, M, N, K);
-  run<0, 2, 2, 2, 2, 2, 1, 1>("full, XCD remap, frag prefetch", A, B, C, M, N, K);
-  run<16, 2, 2, 2, 2, 2, 1, 1>("same, every WG reads A tile 0 (L2-hot)", A, B, C, M, N, K);
-  run<16, 2, 2, 2, 2, 2, 0, 1>("same without remap, A tile 0", A, B, C, M, N, K);
-  run<16, 2, 2, 2, 2, 2, 0, 0>("no fpf, no remap, A tile 0", A, B, C, M, N, K);
+  // (the first launch series runs ~15 % slow -- clocks / caches warming up: it is repeated)
+  run<0, 2, 2, 2, 2, 2>("two-buffer pipeline, no remap (warm-up)", A, B, C, M, N, K);
+  run<0, 2, 2, 2, 2, 2>("two-buffer pipeline, no remap", A, B, C, M, N, K);
+  run<0, 2, 2, 2, 2, 2, 1>("+ XCD-contiguous tile walk", A, B, C, M, N, K);
+  run<0, 2, 2, 2, 2, 2, 0, 1>("+ fragment prefetch (no remap)", A, B, C, M, N, K);
+  run<0, 2, 2, 2, 2, 2, 1, 1>("+ fragment prefetch + remap", A, B, C, M, N, K);
+  run2<0, 2>("v2: full-line loads, pair stages, fpf, remap", A, B, C, M, N, K);
+  run<16, 2, 2, 2, 2, 2, 1, 1>("fpf + remap, every WG reads A tile 0 (L2-hot A)", A, B, C, M, N, K);
+  run<0, 2, 4, 2, 2, 1, 1, 1>("wave tile 64x128 (128x256), 4 waves, 1 wg/CU", A, B, C, M, N, K);
+  run<0, 4, 2, 2, 2, 1, 1, 1>("wave tile 128x64 (256x128), 4 waves, 1 wg/CU", A, B, C, M, N, K);
+  // ablations: registers hold synthetic, loop-invariant data in the "no loads" arms -- the split is hoisted with them and
+  // the MFMAs chew on regular bit patterns at a higher clock: upper bounds of the structure, not prices of the loads
+  run2<2, 2>("v2 without the split (raw bits stored)", A, B, C, M, N, K);
+  run2<1, 2>("v2 without global loads (and without split: hoisted)", A, B, C, M, N, K);
+  run<15, 2, 2, 2, 2, 2>("MFMAs + barriers only", A, B, C, M, N, K);
   return 0;
 }

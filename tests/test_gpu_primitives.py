@@ -333,3 +333,45 @@ def test_linear_time_major_layouts(H):
         linear_bwd_weight_raw(dyd.data_ptr(), O, xd.data_ptr(), I, dw, B * T, I, O, B=B, T=T, x_shift=shift,
                               dy_tm=dy_tm_f, x_tm=x_tm_f)
         assert rel_err(dw, wref) < 2e-6, (dy_tm_f, x_tm_f, shift)
+
+
+@pytest.mark.parametrize('B,T,Cin,C,K', [(2, 9, 8, 8, 4), (3, 37, 12, 12, 5), (4, 700, 80, 64, 8), (32, 128, 256, 128, 3)])
+def test_bank_bn_pool_fused_equals_three_passes(H, B, T, Cin, C, K):
+    """BatchNorm apply + MaxPool1d(2,1,1) in one pass (ft_bn_pool_from_partials / ft_bn_pool_bwd) against the separate
+    kernels AND against torch (common_layers.py:100-105) -- the bank's ReLU leaves runs of equal zeros, so the pooling
+    ties (first maximal element takes the gradient) are exercised on every channel."""
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(B, T, Cin, generator=g)
+    ws = [torch.randn(C, Cin, k, generator=g) * 0.2 for k in range(1, K + 1)]
+    gamma = torch.randn(K * C, generator=g)          # negative gammas flip the order of z relative to y
+    beta = torch.randn(K * C, generator=g)
+    dout = torch.randn(B, T, K * C, generator=g)
+    wp_all = torch.cat([H.conv_pack_weight(dev(w)).reshape(-1) for w in ws])
+    res = {}
+    for fused in (True, False):
+        rm, rv = torch.zeros(K * C).cuda(), torch.ones(K * C).cuda()
+        ybank, part, nch = H.conv_bank_fwd_stats(dev(x), wp_all, K, C, relu=True)
+        if fused:
+            assert H.bn_pool_fusable(ybank, C)
+            out, mean, rstd = H.bn_pool_from_partials(part, nch, ybank, dev(gamma), dev(beta), rm, rv, Tout=T, group=C)
+            dy, dg, db = H.bn_pool_bwd(dev(dout), ybank, dev(gamma), dev(beta), mean, rstd, group=C, relu=True)
+        else:
+            z, mean, rstd = H.bn_train_from_partials(part, nch, ybank, dev(gamma), dev(beta), rm, rv, Tout=T, group=C)
+            out = H.maxpool2_fwd(z)
+            dy, dg, db = H.bn_bwd(H.maxpool2_bwd(dev(dout), z), ybank, dev(gamma), mean, rstd, group=C, relu=True)
+        res[fused] = [t.cpu() for t in (out, dy, dg, db, rm, rv)]
+    for a, b, name in zip(res[True], res[False], ('out', 'dy', 'dgamma', 'dbeta', 'running_mean', 'running_var')):
+        assert torch.equal(a, b), name                # same arithmetic, same summation order: bit-equal
+    # torch on the CPU, float64
+    xs = x.double().transpose(1, 2)
+    outs = []
+    for i, w in enumerate(ws):
+        k = i + 1
+        y = torch.relu(torch.nn.functional.conv1d(xs, w.double(), padding=k // 2))
+        y = torch.nn.functional.batch_norm(y, None, None, gamma[i * C:(i + 1) * C].double(), beta[i * C:(i + 1) * C].double(),
+                                           training=True, eps=1e-5)
+        outs.append(y[:, :, :T])
+    zc = torch.cat(outs, dim=1)
+    ref = torch.nn.functional.max_pool1d(zc, kernel_size=2, stride=1, padding=1)[:, :, :T]
+    assert rel_err(res[True][0], ref.transpose(1, 2).detach()) < 2e-5
+    # (the gradients' parity with the reference is pinned end to end: tests/test_gpu_model.py's golden train steps)
