@@ -348,6 +348,9 @@ class FastPitch(nn.Module):
         # run under it; trainer.TrainStep extends it over backward (hip.gemm_precision for a hand-rolled backward).
         self.matmul_dtype = 'fp32'
         self.lr = LengthRegulator()
+        # predictor branches share no graph node with the trunk in training (trainer.TrainStep may run their backward as a
+        # stage of its own)
+        self.independent_predictors = True
         self.dur_pred = SeriesPredictor(num_chars=num_chars, d_model=durpred_d_model, n_heads=durpred_n_heads,
                                         layers=durpred_layers, d_fft=durpred_d_fft, conv1_kernel=conv1_kernel,
                                         conv2_kernel=conv2_kernel, dropout=durpred_dropout)
@@ -448,7 +451,8 @@ class FastPitch(nn.Module):
         if not hasattr(self, '_streams'):
             self._streams = {}
         if key not in self._streams:
-            self._streams[key] = torch.cuda.Stream(device=device)
+            from .model import _side_priority
+            self._streams[key] = torch.cuda.Stream(device=device, priority=_side_priority())
         return self._streams[key]
 
     def get_step(self) -> int:

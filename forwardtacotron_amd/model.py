@@ -37,6 +37,11 @@ def _seed() -> int:
     return (st['base'] + 0x9E3779B97F4A7C15 * st['n']) & ((1 << 62) - 1)
 
 
+def _side_priority() -> int:
+    import os
+    return -1 if os.environ.get('FT_PRED_PRIORITY', '1') == '1' else 0
+
+
 def _dropout(x: torch.Tensor, p: float, training: bool) -> torch.Tensor:
     if not training or p <= 0.0:
         return x
@@ -265,6 +270,9 @@ class ForwardTacotron(nn.Module):
         self.padding_value = padding_value
         self.embedding = nn.Embedding(num_chars, embed_dims)
         self.lr = LengthRegulator()
+        # predictor branches share no graph node with the trunk in training (trainer.TrainStep may run their backward as a
+        # stage of its own)
+        self.independent_predictors = True
         self.dur_pred = SeriesPredictor(num_chars=num_chars, emb_dim=series_embed_dims,
                                         conv_dims=durpred_conv_dims, rnn_dims=durpred_rnn_dims,
                                         dropout=durpred_dropout)
@@ -324,6 +332,12 @@ class ForwardTacotron(nn.Module):
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
                                 self.energy_strength, True)                 # -> [B,Tx,2P]
         x = self.lr(x, dur, mel_lens)       # at max(mel_lens) frames, the length pad_packed_sequence returns (:147-152)
+        if self.training and torch.is_grad_enabled() and getattr(self, 'stage_backward', False):
+            # trainer.TrainStep runs the backward in three stages (postnet .. LSTM | predictors | LR .. prenet): the graph
+            # is cut here, below the LSTM, and the trainer feeds the cut's gradient into the lower part itself
+            cut = x.detach().requires_grad_(True)
+            self._cut = (x, cut)
+            x = cut
         x = self.lstm(x, mel_lens, self.padding_value)
         mel = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)        # [B,T,n_mels]
         post = self.postnet(mel, time_major_out=True)                       # [T,B,2Q]
@@ -374,7 +388,9 @@ class ForwardTacotron(nn.Module):
         if not hasattr(self, '_streams'):
             self._streams = {}
         if key not in self._streams:
-            self._streams[key] = torch.cuda.Stream(device=device)
+            # high priority like the trainer's main stream: the predictors' kernels are small and many, behind the trunk's
+            # 1000-workgroup GEMMs in a default-priority queue each of them waits for a free CU (0.25 ms of the step)
+            self._streams[key] = torch.cuda.Stream(device=device, priority=_side_priority())
         return self._streams[key]
 
     def generate(self, x: torch.Tensor, alpha=1.0,

@@ -93,6 +93,9 @@ class MultiFastPitch(nn.Module):
         self.padding_value = padding_value
         self.matmul_dtype = 'fp32'          # or 'bf16': see fastpitch.FastPitch
         self.lr = LengthRegulator()
+        # predictor branches share no graph node with the trunk in training (trainer.TrainStep may run their backward as a
+        # stage of its own)
+        self.independent_predictors = True
         shared = {k: hp[k] for k in ('num_chars', 'conv1_kernel', 'conv2_kernel', 'speaker_emb_dims')}
 
         def predictor(kind, prefix, **more):
@@ -161,7 +164,8 @@ class MultiFastPitch(nn.Module):
         if not hasattr(self, '_streams'):
             self._streams = {}
         if key not in self._streams:
-            self._streams[key] = torch.cuda.Stream(device=x.device)
+            from .model import _side_priority
+            self._streams[key] = torch.cuda.Stream(device=x.device, priority=_side_priority())
         side = self._streams[key]
         side.wait_stream(main)
         with torch.cuda.stream(side):

@@ -11,7 +11,8 @@ import torch.nn as nn
 
 from . import hip as H
 from . import ops
-from .model import (BatchNormConv, CBHG, GRU, LSTM, LengthRegulator, NUM_CHARS_DEFAULT, PAD_VALUE, _dropout)
+from .model import (BatchNormConv, CBHG, GRU, LSTM, LengthRegulator, NUM_CHARS_DEFAULT, PAD_VALUE, _dropout,
+                    _side_priority)
 
 
 class SeriesPredictor(nn.Module):
@@ -99,6 +100,9 @@ class MultiForwardTacotron(nn.Module):
         E, P, Q, S = hp['embed_dims'], hp['prenet_dims'], hp['postnet_dims'], hp['speaker_emb_dims']
         self.embedding = nn.Embedding(hp['num_chars'], E)
         self.lr = LengthRegulator()
+        # predictor branches share no graph node with the trunk in training (trainer.TrainStep may run their backward as a
+        # stage of its own)
+        self.independent_predictors = True
 
         def predictor(kind, prefix, **more):
             # NB (reference quirk, multi_forward_tacotron.py:135-157): speaker_emb_dims is NOT forwarded to the
@@ -155,6 +159,12 @@ class MultiForwardTacotron(nn.Module):
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
                                 self.energy_strength, False)
         x = self.lr(x, dur, mel_lens)       # at max(mel_lens) frames, the length pad_packed_sequence returns
+        if self.training and torch.is_grad_enabled() and getattr(self, 'stage_backward', False):
+            # trainer.TrainStep runs the backward in three stages (postnet .. LSTM | predictors | LR .. prenet): the graph
+            # is cut here, below the LSTM, and the trainer feeds the cut's gradient into the lower part itself
+            cut = x.detach().requires_grad_(True)
+            self._cut = (x, cut)
+            x = cut
         x = self.lstm(x, mel_lens, self.padding_value)
         mel = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)
         post = self.postnet(mel, time_major_out=True)
@@ -231,7 +241,7 @@ class MultiForwardTacotron(nn.Module):
         if not hasattr(self, '_streams'):
             self._streams = {}
         if key not in self._streams:
-            self._streams[key] = torch.cuda.Stream(device=device)
+            self._streams[key] = torch.cuda.Stream(device=device, priority=_side_priority())
         return self._streams[key]
 
     def get_step(self) -> int:

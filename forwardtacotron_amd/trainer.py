@@ -101,12 +101,16 @@ class TrainStep:
         pl = ops.masked_l1(pred['pitch'], pitch_target.unsqueeze(1), batch['x_len'])
         el = ops.masked_l1(pred['energy'], energy_target.unsqueeze(1), batch['x_len'])
         loss = m1 + m2 + c['dur_loss_factor'] * dl + c['pitch_loss_factor'] * pl + c['energy_loss_factor'] * el
+        # the same total as two roots (see _step: the predictors' backward is issued first)
+        side = c['dur_loss_factor'] * dl + c['pitch_loss_factor'] * pl + c['energy_loss_factor'] * el
         out = {'mel': m1, 'mel_post': m2, 'dur': dl, 'pitch': pl, 'energy': el}
         if 'pitch_cond' in pred:        # multispeaker: CrossEntropyLoss(ignore_index=0), multi_forward_trainer.py:34,88
             ce = ops.cross_entropy(pred['pitch_cond'], batch['pitch_cond'], 0)
             loss = loss + c.get('pitch_cond_loss_factor', 0.1) * ce
+            side = side + c.get('pitch_cond_loss_factor', 0.1) * ce
             out['pitch_cond'] = ce
         out['loss'] = loss
+        out['_roots'] = (side, m1 + m2)
         return out
 
     def step(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -147,8 +151,16 @@ class TrainStep:
         packs.refresh()                     # every conv pack / weight transpose of this step, one launch
         H.pack_cache = packs
         old_precision = H.set_gemm_precision(getattr(model, 'matmul_dtype', 'fp32'))    # forward AND backward
+        # staged backward (see below): only this trainer asks the model to cut its graph below the LSTM
+        staged = (getattr(model, 'independent_predictors', False) and hasattr(model, 'lstm')
+                  and os.environ.get('FT_STAGED_BACKWARD', '1') == '1')
+        model.stage_backward = staged
+        model._cut = None
         try:
-            pred = model(batch)
+            try:
+                pred = model(batch)
+            finally:
+                model.stage_backward = False
             L = self.losses(pred, batch, pitch_target, energy_target)
             self.flat.zero_grad()
             self.reducer.start()
@@ -158,7 +170,33 @@ class TrainStep:
             self.sink.defer = bool(getattr(model, 'wgrad_defer', False)) and os.environ.get('FT_WGRAD_DEFER', '1') == '1'
             ops.set_grad_sink(self.sink)
             try:
-                L['loss'].backward()
+                # The predictor branches share nothing with the trunk (each has its own embedding; the trunk is fed the
+                # batch's pitch / energy / pitch_cond, forward_tacotron.py:129-159) and run on their own side stream.
+                # One backward over the summed loss issues their nodes LAST (autograd orders ready nodes by creation
+                # order, the predictors were created first): 1.9 ms of predictor BPTT + conv backward at the end of the
+                # step with the main stream idle.  Issued FIRST they collide with the trunk's recurrences instead (a
+                # persistent LSTM BPTT fills its XCD slots: it would wait for every queued predictor BPTT, +1 ms).  So
+                # the backward runs in three stages: postnet .. LSTM (down to the cut below the LSTM), then the
+                # predictors -- their BPTT kernels queue behind the LSTM's and run beside the prenet's GEMMs -- then
+                # LR .. prenet, whose GRU fits next to a predictor's.
+                side_root, main_root = L.pop('_roots')
+                cut = getattr(model, '_cut', None)
+                model._cut = None
+                if staged and cut is not None:
+                    main_root.backward()
+                    # backward() ends by making the CALLING stream wait for every stream it ran nodes on: called from
+                    # the main stream the predictors' stage would simply be inserted into the critical path.  It is
+                    # issued from the predictors' own stream; the step's final join picks that stream up.
+                    here = torch.cuda.current_stream()
+                    pstream = model._side_stream(side_root.device)
+                    pstream.wait_stream(here)
+                    with torch.cuda.stream(pstream):
+                        side_root.backward()
+                    side_root.record_stream(pstream)
+                    self.sink.used.add(pstream)
+                    cut[0].backward(cut[1].grad)
+                else:
+                    L['loss'].backward()
                 ops.flush_deferred()
             finally:
                 ops.set_grad_sink(None)
