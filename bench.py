@@ -82,14 +82,15 @@ def _bank_describe(a, k):
 
 
 def dominant_kernel_roofline(bank_ms):
-    """The dominant GEMM-shaped launch of the step -- the postnet conv bank forward, one ft_gemm_rows_b3_kernel<2,2>
+    """The dominant GEMM-shaped launch of the step -- the postnet conv bank forward, one ft_gemm_rows_b3p_kernel<3>
     launch (M = 32*842 rows, 8 members k=1..8, Cin 80 -> 256: 2*B*(T+1)*80*256*36 FLOP)."""
     B, T, Cin, C, K = BANK_SHAPE
     ms = sum(bank_ms) / max(len(bank_ms), 1)
     flops = 2.0 * B * (T + 1) * Cin * C * (K * (K + 1) // 2)
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     b3 = os.environ.get('FT_GEMM_B3', '1') != '0'
-    kernel = 'ft_gemm_rows_b3_kernel<2,2>' if b3 else 'ft_gemm_rows_kernel<2,2,NT>'
+    piped = os.environ.get('FT_GEMM_PIPE', '1') != '0'
+    kernel = ('ft_gemm_rows_b3p_kernel<3>' if piped else 'ft_gemm_rows_b3_kernel<2,2>') if b3 else 'ft_gemm_rows_kernel<2,2,NT>'
     out = {'bound': 'mfma', 'kernel': kernel + ' (postnet conv bank fwd)',
            'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
            'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4),
