@@ -225,6 +225,46 @@ static bool stats_in_epilogue() {
   return v == 1;
 }
 
+// Token-side convolutions (B*T = 4096 rows here) have too few 128x128 output tiles to fill the chip and used to run on
+// the 64x64 f32 kernel at 45-70 TF (prenet projection, 4096 x 256 x (3 x 4096): 376 us).  With k >= 2 taps the taps are
+// INDEPENDENT tasks of one launch instead -- tiles x k >= 192 workgroups on the pipelined split kernel, each writing its
+// own fp32 slab -- followed by one ordered sum (+ReLU) over the k slabs: deterministic, the taps are merely added in tap
+// order after instead of inside the accumulator.  FT_CONV_TAP_SPLIT=0 disables.
+static bool conv_tap_split(int B, int Tout, int Cout, int k) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("FT_CONV_TAP_SPLIT");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  const long tiles = (long)ft_cdiv((long)B * Tout, 128) * ft_cdiv(Cout, 128);
+  return on && k >= 2 && k <= FT_MAX_TASKS && Cout > 64 && Cout % 4 == 0 && (long)B * Tout > 64 && tiles < 192 &&
+         tiles * k >= 192;
+}
+static size_t conv_stats_bytes_aligned(int B, int Tout, int Cout) {
+  return (ft_conv_stats_workspace(B, Tout, Cout) + 255) & ~(size_t)255;
+}
+
+__global__ __launch_bounds__(256) void ft_tap_slab_sum4_kernel(const float4* __restrict__ slab, float4* __restrict__ y,
+                                                               long total4, int S, int relu) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  float4 a = slab[i];
+  for (int s = 1; s < S; ++s) {
+    const float4 v = slab[(long)s * total4 + i];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (relu) {
+    a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+  }
+  y[i] = a;
+}
+
+size_t ft_conv1d_fwd_stats_workspace(int B, int Tout, int Cout, int k) {
+  size_t n = conv_stats_bytes_aligned(B, Tout, Cout);
+  if (conv_tap_split(B, Tout, Cout, k)) n += (size_t)k * B * Tout * Cout * sizeof(float);
+  return n;
+}
+
 int ft_conv1d_fwd_stats(const float* x, long ldx, const float* wp, float* y, long ldy, int B, int T, int Cin, int Cout,
                         int k, int Tout, int relu, double* partial, size_t partial_bytes, int* nchunks,
                         void* stream) {
@@ -233,6 +273,24 @@ int ft_conv1d_fwd_stats(const float* x, long ldx, const float* wp, float* y, lon
   FT_REQUIRE(partial_bytes >= ft_conv_stats_workspace(B, Tout, Cout), "conv1d_fwd_stats: partial buffer too small");
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
+  if (conv_tap_split(B, Tout, Cout, k) && partial_bytes >= ft_conv1d_fwd_stats_workspace(B, Tout, Cout, k) &&
+      ((uintptr_t)y % 16 == 0)) {
+    float* slab = reinterpret_cast<float*>(reinterpret_cast<char*>(partial) + conv_stats_bytes_aligned(B, Tout, Cout));
+    const long mn = (long)B * Tout * Cout;
+    for (int j = 0; j < k; ++j) {
+      FtGemmTask& t = b.t[j];
+      conv_fwd_task(t, x, ldx, wp + (long)j * Cout * Cin, slab + (long)j * mn, Cout, B, T, Cin, Cout, k, Tout, 0);
+      t.taps = 1;
+      t.amap.shift0 = -(k / 2) + j;
+      t.amap.shift_step = 0;
+    }
+    int rc = ft_launch_gemm_rows(&b, k, false, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ft_tap_slab_sum4_kernel, dim3(ft_cdiv(mn / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)slab, (float4*)y, mn / 4, k, relu);
+    *nchunks = ft_bn_stat_partials(y, B, Tout, Cout, 0, partial, (hipStream_t)stream);
+    return ft_check_launch("conv1d_fwd_stats (tap split)");
+  }
   conv_fwd_task(b.t[0], x, ldx, wp, y, ldy, B, T, Cin, Cout, k, Tout, relu);
   b.t[0].stat = stats_in_epilogue() ? partial : nullptr;
   b.t[0].stat_ld = Cout;

@@ -339,7 +339,7 @@ def conv1d_fwd_stats(x: torch.Tensor, wp: torch.Tensor, relu: bool, Tout: int):
     B, T, Cin = x.shape
     k, Cout, _ = wp.shape
     y = torch.empty(B, Tout, Cout, device=x.device, dtype=x.dtype)
-    nbytes = _lib.query('ft_conv_stats_workspace', B, Tout, Cout)
+    nbytes = _lib.query('ft_conv1d_fwd_stats_workspace', B, Tout, Cout, k)
     part = workspace(nbytes, x.device)
     n = ctypes.c_int(0)
     _lib.call('ft_conv1d_fwd_stats', _p(x), Cin, _p(wp), _p(y), Cout, B, T, Cin, Cout, k, Tout, int(relu), _p(part),

@@ -195,8 +195,12 @@ size_t ft_bn_workspace(int B, int Tbuf, int C);
  * activation is not read back for the statistics; launches that do not take the 128x128 kernel (token-side shapes) run
  * the stand-alone column pass instead -- either way *nchunks (HOST int) tells ft_bn_train_from_partials how many partial
  * rows to finalize (ordered sum; mean / biased var / running stats as ft_bn_train_fwd) before it normalises.
- * conv1d: y contiguous [B,Tout,Cout].  conv_bank: training-mode bank buffer [B,T+1,K*C]; odd-k members count T rows. */
+ * conv1d: y contiguous [B,Tout,Cout].  conv_bank: training-mode bank buffer [B,T+1,K*C]; odd-k members count T rows.
+ * ft_conv1d_fwd_stats_workspace >= ft_conv_stats_workspace: it adds room for per-tap output slabs where a token-side
+ * convolution (too few 128x128 tiles to fill the chip) runs its k taps as independent tasks followed by one ordered sum;
+ * a caller that passes only ft_conv_stats_workspace bytes simply gets the single-task form. */
 size_t ft_conv_stats_workspace(int B, int Tbuf, int C);
+size_t ft_conv1d_fwd_stats_workspace(int B, int Tout, int Cout, int k);
 int ft_conv1d_fwd_stats(const float* x, long ldx, const float* wp, float* y, long ldy, int B, int T, int Cin, int Cout,
                         int k, int Tout, int relu, double* partial, size_t partial_bytes, int* nchunks, void* stream);
 int ft_conv_bank_fwd_stats(const float* x, long ldx, const float* wp_all, float* ybank, int B, int T, int Cin, int C,
