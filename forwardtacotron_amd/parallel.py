@@ -7,6 +7,7 @@ cut into buckets; a post-accumulate hook launches an asynchronous sum all-reduce
 exchange overlaps the remaining backward (the 841-step recurrences dominate).
 Nothing here is model specific, which is what lets the CPU/gloo tests exercise the N>1 path.
 """
+import os
 import re
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -87,6 +88,9 @@ class BucketedAllReduce:
         self.flat = flat
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # FT_DP_FORCE_COLLECTIVE=1: a one-rank group still runs every bucket through the backend (a sum over one rank is
+        # the identity) -- lets a one-GPU box execute the RCCL launch / communication-stream path for real
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get('FT_DP_FORCE_COLLECTIVE') == '1')
         # bucket boundaries over the flat layout, walking parameters from the END (first grads ready)
         self.buckets: List[Tuple[int, int]] = []
         self.param_bucket: List[int] = [0] * len(flat.params)
@@ -117,7 +121,7 @@ class BucketedAllReduce:
         self.seen = set()
         self.held = None                # set of parameter indices a gradient sink still owes (ops.GradSink.held)
         self.comm_stream = None
-        if self.world > 1:
+        if self.active:
             for j, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(j))
 
@@ -133,7 +137,7 @@ class BucketedAllReduce:
     def notify(self, j: int) -> None:
         """Gradient of parameter j is complete (called by the autograd hook, or by the gradient sink when the
         backward kernels write the flat buffer directly)."""
-        if not self.armed or self.world <= 1:
+        if not self.armed or not self.active:
             return
         # A parameter can be announced twice in one backward: by the gradient sink when its kernel is enqueued and
         # again by autograd's post-accumulate hook (the engine still visits the leaf although the Function returned
@@ -181,7 +185,7 @@ class BucketedAllReduce:
     def finish(self) -> None:
         """After backward(): the flat gradient holds the SUM over ranks (divide by world in the optimiser)."""
         self.armed = False
-        if self.world <= 1:
+        if not self.active:
             return
         for b in range(len(self.buckets)):
             self._launch(b)

@@ -94,3 +94,51 @@ def test_train_step_world2_matches_mean_gradient(bucket_bytes):
         want = p0[n] - LR * mhat / (vhat.sqrt() + 1e-8)
         live = g[n].abs() > 1e-6
         assert float((sd0[n][live] - want[live]).abs().max() if live.any() else 0.0) < 2e-5, n
+
+
+def _rccl_worker(port, bucket_bytes, q):
+    import torch.distributed as dist
+    from forwardtacotron_amd.trainer import TrainStep
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['FT_DP_FORCE_COLLECTIVE'] = '1'
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    m = _model()
+    ts = TrainStep(m, lr=LR, train_cfg=TRAIN_CFG, bucket_bytes=bucket_bytes)
+    assert ts.reducer.active and ts.reducer.world == 1
+    norms = []
+    for i in range(2):
+        out = ts.step({k: v.cuda() for k, v in _batch(i).items()})
+        norms.append(float(out['grad_norm']))
+    torch.cuda.synchronize()
+    launched = sum(ts.reducer.launched)
+    q.put(({k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, norms, len(ts.reducer.buckets), launched,
+           ts.reducer.comm_stream is not None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_bytes', [4096])
+def test_train_step_over_rccl_one_rank_group(bucket_bytes):
+    """The box has one card, so RCCL cannot be given two ranks; what CAN run for real is the whole N>1 code path over
+    the 'nccl' backend (= RCCL) in a one-rank group with FT_DP_FORCE_COLLECTIVE=1: init_process_group(device_id),
+    per-bucket ncclAllReduce launches on the communication stream chained behind the producer streams, the waits before
+    clip + Adam.  A sum over one rank is the identity: two steps must equal the undistributed TrainStep bit for bit."""
+    from forwardtacotron_amd.trainer import TrainStep
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), bucket_bytes, q))
+    p.start()
+    sd, norms, n_buckets, launched, had_comm_stream = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert n_buckets > 1 and launched == n_buckets and had_comm_stream
+    m = _model()
+    ts = TrainStep(m, lr=LR, train_cfg=TRAIN_CFG)
+    want_norms = [float(ts.step({k: v.cuda() for k, v in _batch(i).items()})['grad_norm']) for i in range(2)]
+    torch.cuda.synchronize()
+    assert norms == want_norms
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), torch.from_numpy(sd[k])), k
