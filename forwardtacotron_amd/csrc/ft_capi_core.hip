@@ -50,6 +50,35 @@ int ft_device_info(int* cu_count, int* is_gfx950) {
   return FT_OK;
 }
 
+// A stream whose kernels may only use the first `cus_per_xcd` CUs of every XCD (bit i of a HIP CU mask = CU i / 8 of
+// XCD i % 8 on this part: lab/cumask_probe2.hip).  The trainer runs its weight-gradient side stream on such a stream:
+// those GEMMs are one resident wave of long-running workgroups that fill every CU's register file, so the small
+// dependent kernels of the step's critical stream found no slot until a whole GEMM had finished, whatever their priority.
+int ft_stream_create_cu_limited(int cus_per_xcd, void** stream) {
+  FT_REQUIRE(stream != nullptr, "ft_stream_create_cu_limited: null result pointer");
+  int cus = 0, gfx950 = 0;
+  if (ft_device_info(&cus, &gfx950) != FT_OK) return FT_ERR_HIP;
+  const int per = cus / 8;
+  FT_REQUIRE(cus % 8 == 0 && per <= 32 && cus_per_xcd >= 1 && cus_per_xcd <= per,
+             "ft_stream_create_cu_limited: %d CUs per XCD requested, the device has %d CUs", cus_per_xcd, cus);
+  uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 8 * cus_per_xcd; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t s = nullptr;
+  if (hipExtStreamCreateWithCUMask(&s, 8, mask) != hipSuccess) {
+    ft_set_error("ft_stream_create_cu_limited: hipExtStreamCreateWithCUMask failed");
+    return FT_ERR_HIP;
+  }
+  *stream = (void*)s;
+  return FT_OK;
+}
+int ft_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+    ft_set_error("ft_stream_destroy: hipStreamDestroy failed");
+    return FT_ERR_HIP;
+  }
+  return FT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 static int check_tm(const char* what, int rows, int tm_B) {
   if (tm_B > 0 && rows % tm_B != 0) {

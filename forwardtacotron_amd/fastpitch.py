@@ -414,6 +414,9 @@ class FastPitch(nn.Module):
             dur_hat = self.dur_pred(x, src_pad_mask=len_mask).squeeze(-1)
             pitch_hat = self.pitch_pred(x, src_pad_mask=len_mask).transpose(1, 2)
             energy_hat = self.energy_pred(x, src_pad_mask=len_mask).transpose(1, 2)
+            hook = getattr(self, 'predictor_hook', None)   # trainer.TrainStep: the predictors' losses + backward, right here
+            if hook is not None:
+                hook({'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat})
         mel_cl = self._mel(x, len_mask, dur, batch['pitch'], batch['energy'],
                            mel_lens.to(device=x.device, dtype=torch.long))
         x_mel = ops.TransposePadFn.apply(mel_cl, mel.size(2), self.padding_value)

@@ -372,6 +372,9 @@ class ForwardTacotron(nn.Module):
             dur_hat = self.dur_pred(x).squeeze(-1)
             pitch_hat = self.pitch_pred(x).transpose(1, 2)
             energy_hat = self.energy_pred(x).transpose(1, 2)
+            hook = getattr(self, 'predictor_hook', None)   # trainer.TrainStep: the predictors' losses + backward, right here
+            if hook is not None:
+                hook({'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat})
 
         mel_cl, post_cl = self._trunk(x, dur, pitch, energy, mel_lens.to(device=x.device, dtype=torch.long))
         Tout = mel.size(2)

@@ -173,6 +173,9 @@ class MultiFastPitch(nn.Module):
             pitch_hat = self.pitch_pred(x, pitch_cond, semb, src_pad_mask=len_mask).transpose(1, 2)
             pitch_cond_hat = self.pitch_cond_pred(x, semb, src_pad_mask=len_mask)
             energy_hat = self.energy_pred(x, semb, src_pad_mask=len_mask).transpose(1, 2)
+            hook = getattr(self, 'predictor_hook', None)   # trainer.TrainStep: the predictors' losses + backward, right here
+            if hook is not None:
+                hook({'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat, 'pitch_cond': pitch_cond_hat})
         mel_cl = self._mel(x, semb, len_mask, dur, batch['pitch'], batch['energy'],
                            mel_lens.to(device=x.device, dtype=torch.long))
         x_mel = ops.TransposePadFn.apply(mel_cl, mel.size(2), self.padding_value)

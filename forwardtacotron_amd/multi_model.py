@@ -201,6 +201,9 @@ class MultiForwardTacotron(nn.Module):
             dur_hat = self.dur_pred(x, pitch_cond, semb).squeeze(-1)
             pitch_hat = self.pitch_pred(x, pitch_cond, semb).transpose(1, 2)
             energy_hat = self.energy_pred(x, semb).transpose(1, 2)
+            hook = getattr(self, 'predictor_hook', None)   # trainer.TrainStep: the predictors' losses + backward, right here
+            if hook is not None:
+                hook({'dur': dur_hat, 'pitch': pitch_hat, 'energy': energy_hat, 'pitch_cond': pitch_cond_hat})
 
         mel_cl, post_cl = self._trunk(x, semb, dur, pitch, energy, mel_lens.to(device=x.device, dtype=torch.long))
         Tout = mel.size(2)

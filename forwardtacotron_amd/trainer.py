@@ -61,7 +61,7 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = BucketedAllReduce(self.flat, process_group, bucket_bytes)
         # weight gradients are written straight into the flat buffer, the GEMM-shaped ones on a side stream
-        self.wgrad_stream = torch.cuda.Stream(device=dev)
+        self.wgrad_stream = self._make_wgrad_stream(dev)
         self.reducer.streams.add(self.wgrad_stream)
         self.sink = ops.GradSink({p.data_ptr(): (i, p.grad) for i, p in enumerate(self.flat.params)},
                                  stream=self.wgrad_stream, on_write=self.reducer.notify)
@@ -71,6 +71,22 @@ class TrainStep:
                             if os.environ.get('FT_MAIN_PRIORITY', '1') == '1' else None)
         self._packs_base = 0
         self._gc_frozen = os.environ.get('FT_GC_FREEZE', '1') != '1'
+
+    @staticmethod
+    def _make_wgrad_stream(dev) -> 'torch.cuda.Stream':
+        """The weight-gradient side stream.  FT_WGRAD_CUS=n (1..31) restricts it to n CUs of every XCD
+        (ft_stream_create_cu_limited): a weight-gradient GEMM is ONE resident wave of long-running workgroups that fills the
+        register file of every CU it may use, so the step's critical stream -- however high its priority -- found no slot
+        for its small dependent kernels until the whole GEMM had drained; a few CUs per XCD kept out of the side stream's
+        reach are always open to it.  0 / 32: an ordinary stream."""
+        import ctypes
+        n = int(os.environ.get('FT_WGRAD_CUS', '0'))
+        if n <= 0 or n >= 32:
+            return torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev):
+            h = ctypes.c_void_p()
+            _lib.call('ft_stream_create_cu_limited', n, ctypes.byref(h))
+        return torch.cuda.ExternalStream(h.value, device=dev)
 
     def _weight_packs(self) -> H.PackCache:
         """the re-laid-out weight copies of this model (hip.PackCache), rebuilt only if the flat buffer moved"""
@@ -94,24 +110,30 @@ class TrainStep:
         return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
                 'step': torch.tensor(self.opt_step), 'lr': torch.tensor(self.lr)}
 
-    def losses(self, pred: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], pitch_target, energy_target):
-        """forward_trainer.py:83-93"""
+    def side_losses(self, pred: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], pitch_target, energy_target,
+                    dur_target=None):
+        """the predictors' loss terms (forward_trainer.py:86-93) and their weighted sum"""
         c = self.cfg
-        m1 = ops.masked_l1(pred['mel'], batch['mel'], batch['mel_len'])
-        m2 = ops.masked_l1(pred['mel_post'], batch['mel'], batch['mel_len'])
-        dl = ops.masked_l1(pred['dur'].unsqueeze(1), batch['dur'].unsqueeze(1), batch['x_len'])
+        dur_t = batch['dur'] if dur_target is None else dur_target
+        dl = ops.masked_l1(pred['dur'].unsqueeze(1), dur_t.unsqueeze(1), batch['x_len'])
         pl = ops.masked_l1(pred['pitch'], pitch_target.unsqueeze(1), batch['x_len'])
         el = ops.masked_l1(pred['energy'], energy_target.unsqueeze(1), batch['x_len'])
-        loss = m1 + m2 + c['dur_loss_factor'] * dl + c['pitch_loss_factor'] * pl + c['energy_loss_factor'] * el
-        # the same total as two roots (see _step: the predictors' backward is issued first)
         side = c['dur_loss_factor'] * dl + c['pitch_loss_factor'] * pl + c['energy_loss_factor'] * el
-        out = {'mel': m1, 'mel_post': m2, 'dur': dl, 'pitch': pl, 'energy': el}
+        out = {'dur': dl, 'pitch': pl, 'energy': el}
         if 'pitch_cond' in pred:        # multispeaker: CrossEntropyLoss(ignore_index=0), multi_forward_trainer.py:34,88
             ce = ops.cross_entropy(pred['pitch_cond'], batch['pitch_cond'], 0)
-            loss = loss + c.get('pitch_cond_loss_factor', 0.1) * ce
             side = side + c.get('pitch_cond_loss_factor', 0.1) * ce
             out['pitch_cond'] = ce
-        out['loss'] = loss
+        return out, side
+
+    def losses(self, pred: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], pitch_target, energy_target):
+        """forward_trainer.py:83-93"""
+        m1 = ops.masked_l1(pred['mel'], batch['mel'], batch['mel_len'])
+        m2 = ops.masked_l1(pred['mel_post'], batch['mel'], batch['mel_len'])
+        out, side = self.side_losses(pred, batch, pitch_target, energy_target)
+        out = dict(mel=m1, mel_post=m2, **out)
+        out['loss'] = m1 + m2 + side
+        # the same total as two roots (see _step: the predictors' backward is a stage of its own)
         out['_roots'] = (side, m1 + m2)
         return out
 
@@ -153,25 +175,63 @@ class TrainStep:
         packs.refresh()                     # every conv pack / weight transpose of this step, one launch
         H.pack_cache = packs
         old_precision = H.set_gemm_precision(getattr(model, 'matmul_dtype', 'fp32'))    # forward AND backward
+        independent = bool(getattr(model, 'independent_predictors', False))
+        # EARLY predictor backward (FT_PRED_BWD_EARLY=1, off by default): the predictors' loss terms depend on nothing but
+        # the predictors' own outputs and the batch's targets (forward_trainer.py:86-93), so their whole backward can be
+        # issued on the predictors' stream right behind their forward, INSIDE the model's forward (model.predictor_hook),
+        # beside the trunk's forward recurrences instead of in the tail of the step.  Measured:
+        # the tail does not get shorter (it is bound by the main stream's own chain and the LSTM's weight gradients, the
+        # predictors' stage ran in their shadow) while the LSTM's forward recurrence stretches 4.1 -> 5.5 ms beside the
+        # predictors' BPTT kernels: 24.6 -> 25.8 ms.  Same gradients bit for bit either way (tests run both).
+        early = independent and os.environ.get('FT_PRED_BWD_EARLY', '0') == '1'
         # staged backward (see below): only this trainer asks the model to cut its graph below the LSTM
-        staged = (getattr(model, 'independent_predictors', False) and hasattr(model, 'lstm')
+        staged = (not early and independent and hasattr(model, 'lstm')
                   and os.environ.get('FT_STAGED_BACKWARD', '1') == '1')
         model.stage_backward = staged
         model._cut = None
+        side_terms: Dict[str, torch.Tensor] = {}
+
+        def arm_sink():
+            self.sink.inline_rows = int(getattr(model, 'wgrad_inline_rows', 0))
+            # models with recurrences queue their side-stream weight gradients and issue them beside the next BPTT kernel
+            self.sink.defer = bool(getattr(model, 'wgrad_defer', False)) and os.environ.get('FT_WGRAD_DEFER', '1') == '1'
+
+        def predictor_hook(p: Dict[str, torch.Tensor]) -> None:
+            # called by the model on the predictors' stream, right behind their forward
+            arm_sink()
+            # the LengthRegulator clamps batch['dur'] in place (on the main stream, possibly at this very moment) and the
+            # reference's loss sees the clamped tensor (forward_trainer.py:79-86): clamp a copy, either read gives the same
+            terms, root = self.side_losses(p, batch, pitch_target, energy_target, dur_target=batch['dur'].clamp(min=0.0))
+            root.backward()                 # ends by joining the CALLING stream (this one) with the streams it used
+            self.sink.used.add(torch.cuda.current_stream())
+            side_terms.update({k: v.detach() for k, v in terms.items()})
+            side_terms['_root'] = root.detach()
+
         try:
+            self.flat.zero_grad()
+            self.reducer.start()
+            self.sink.begin_step()
+            if early:
+                model.predictor_hook = predictor_hook
+                ops.set_grad_sink(self.sink)
             try:
                 pred = model(batch)
             finally:
                 model.stage_backward = False
-            L = self.losses(pred, batch, pitch_target, energy_target)
-            self.flat.zero_grad()
-            self.reducer.start()
-            self.sink.begin_step()
-            self.sink.inline_rows = int(getattr(model, 'wgrad_inline_rows', 0))
-            # models with recurrences queue their side-stream weight gradients and issue them beside the next BPTT kernel
-            self.sink.defer = bool(getattr(model, 'wgrad_defer', False)) and os.environ.get('FT_WGRAD_DEFER', '1') == '1'
+                model.predictor_hook = None
+            arm_sink()
             ops.set_grad_sink(self.sink)
-            try:
+            for v in side_terms.values():       # allocated on the predictors' stream, read from here on
+                v.record_stream(torch.cuda.current_stream())
+            if early and '_root' in side_terms:
+                m1 = ops.masked_l1(pred['mel'], batch['mel'], batch['mel_len'])
+                m2 = ops.masked_l1(pred['mel_post'], batch['mel'], batch['mel_len'])
+                (m1 + m2).backward()
+                ops.flush_deferred()
+                L = dict(mel=m1, mel_post=m2, **{k: v for k, v in side_terms.items() if k != '_root'})
+                L['loss'] = m1.detach() + m2.detach() + side_terms['_root']
+            else:
+                L = self.losses(pred, batch, pitch_target, energy_target)
                 # The predictor branches share nothing with the trunk (each has its own embedding; the trunk is fed the
                 # batch's pitch / energy / pitch_cond, forward_tacotron.py:129-159) and run on their own side stream.
                 # One backward over the summed loss issues their nodes LAST (autograd orders ready nodes by creation
@@ -200,9 +260,8 @@ class TrainStep:
                 else:
                     L['loss'].backward()
                 ops.flush_deferred()
-            finally:
-                ops.set_grad_sink(None)
         finally:
+            ops.set_grad_sink(None)
             H.pack_cache = None
             H.set_gemm_precision(old_precision)
         cur = torch.cuda.current_stream()

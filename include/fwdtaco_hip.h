@@ -332,6 +332,12 @@ int ft_rnn_set_max_spins(int max_spins);
  * precede whatever the waiting stream launches next and no longer count against it.  Optional -- without it the
  * bookkeeping is merely conservative. */
 int ft_rnn_note_join(void* waiting_stream, void* joined_stream);
+/* A HIP stream restricted to the first `cus_per_xcd` CUs of every XCD (hipExtStreamCreateWithCUMask).  New work, no
+ * reference counterpart (the reference is single-stream, trainer/forward_trainer.py:69-99): trainer.TrainStep puts its
+ * weight-gradient side stream on one, so that the one-wave weight-gradient GEMMs leave a few CUs per XCD to the small
+ * dependent kernels of the step's critical stream.  ft_stream_destroy releases it. */
+int ft_stream_create_cu_limited(int cus_per_xcd, void** stream);
+int ft_stream_destroy(void* stream);
 /* (direction, batch group) groups of persistent launches that ran the XCD-local hand-off / the agent-scope one since
  * the library loaded (synchronises the device) */
 int ft_rnn_mode_counts(long* xcd_local_groups, long* agent_scope_groups);

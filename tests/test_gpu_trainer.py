@@ -258,3 +258,32 @@ def test_recurrence_fault_fallback_policy_continues_on_per_step_kernels():
         assert ts.opt_step == 1 and ts.skipped_steps == 1
     finally:
         _lib.lib().ft_rnn_set_persistent(1)
+
+
+@pytest.mark.parametrize('env', [{'FT_PRED_BWD_EARLY': '1'}, {'FT_STAGED_BACKWARD': '0'}, {'FT_WGRAD_CUS': '28'}])
+def test_step_schedule_variants_give_the_same_update(env, monkeypatch):
+    """The backward of a step can be scheduled in several ways -- three stages with the predictors in the middle (the
+    default), one backward call, the predictors' backward issued from inside the forward (model.predictor_hook), the
+    weight-gradient stream restricted to 28 CUs per XCD (ft_stream_create_cu_limited) -- and every parameter's gradient
+    is written by exactly one kernel launch in all of them: the update must not depend on the schedule, bit for bit.
+    The batch has a negative duration: the LengthRegulator clamps it in place and the duration loss must see the clamped
+    value whichever stream computes it first (forward_trainer.py:79-86)."""
+    from forwardtacotron_amd.trainer import TrainStep
+    M = load_npz('tiny_model.npz')
+    batch = {k: v.clone() for k, v in sub(M, 'batch/').items()}
+    batch['dur'][0, 1] = -2.0
+
+    def run():
+        m = _model(sub(M, 'sd/'))
+        ts = TrainStep(m, lr=2e-3, train_cfg=TRAIN_CFG)
+        outs = [ts.step({k: v.clone().cuda() for k, v in batch.items()}) for _ in range(2)]
+        torch.cuda.synchronize()
+        return m.state_dict(), [{k: float(v) for k, v in o.items()} for o in outs]
+
+    sd0, out0 = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sd1, out1 = run()
+    assert out0 == out1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
