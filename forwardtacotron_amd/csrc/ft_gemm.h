@@ -119,6 +119,8 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream);
 int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
                          hipStream_t stream);
+// ft_planes.hip: planes pointer for a B operand (first row / k chunk of the launch) or nullptr
+const void* ft_planes_lookup(const float* b, long ldb, long rows_needed);
 bool ft_gemm_b3_enabled();
 // 0 = fp32-exact (default), 1 = bf16 operands / fp32 accumulate on every NT-form fast launch (ft_set_gemm_precision)
 int ft_gemm_precision();

@@ -19,6 +19,7 @@
 // outputs -- what autocast-style bf16 matmuls compute.  Selected per process with ft_set_gemm_precision(1); the
 // fp32-exact three-plane form (NP = 3) is the default everywhere else.
 #include "ft_gemm.h"
+#include "ft_split.h"
 
 namespace {
 
@@ -39,24 +40,12 @@ __device__ __forceinline__ float4 ld4_sel(const float* p, const float* safe, boo
 // r2 = r1 - mid (exact), lo = rn(r2) -- |x - hi - mid - lo| <= 2^-27 |x|, tighter than the truncation split's 2^-24, at
 // 5.5 VALU instructions per element instead of 8 (and / sub / and / sub + three shift-packs): the split is what bounds
 // this kernel, not the matrix pipe.
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned rn_pack(float a, float b) {
-  const bf16x2v p = {(__bf16)a, (__bf16)b};
-  return __builtin_bit_cast(unsigned, p);
-}
-// the packed value is made opaque (an empty asm: no instruction) before it is taken apart: with the conversion visible,
-// "hi << 16" becomes a SECOND v_cvt_pk_bf16_f32 of (a, 0) -- one more VALU per pair and level.  [Real inline-asm
-// instructions are not an option: sched_group_barrier does not count them as VALU and the MFMA interleave falls apart.]
+// (definition shared with the once-per-step weight split: ft_split.h)
 // The file is built with -fno-slp-vectorize: the SLP pass packs the two subtractions into a v_pk_add_f32, which costs
 // more than two v_sub_f32 beside MFMAs.
+__device__ __forceinline__ unsigned rn_pack(float a, float b) { return ft_rn_pack(a, b); }
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = rn_pack(a, b);
-  asm("" : "+v"(hi));
-  const float a1 = a - __uint_as_float(hi << 16), b1 = b - __uint_as_float(hi & 0xFFFF0000u);
-  mid = rn_pack(a1, b1);
-  asm("" : "+v"(mid));
-  const float a2 = a1 - __uint_as_float(mid << 16), b2 = b1 - __uint_as_float(mid & 0xFFFF0000u);
-  lo = rn_pack(a2, b2);
+  ft_split_pair(a, b, hi, mid, lo);
 }
 __device__ __forceinline__ void split3(const float4& v, u16x4& hi, u16x4& mid, u16x4& lo) {
   unsigned h[2], m[2], l[2];
@@ -335,7 +324,14 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
 // lanes' ds_read_b128 / ds_write_b128 over all 64 banks with no padding column.  A thread stages 8 k of one A row and one
 // B row per stage (two float4 each, k0 + 4h and k0 + 8 + 4h so the wave's two loads are 32 contiguous bytes per row);
 // the k ORDER inside a stage is therefore permuted, identically for A and B, which a dot product does not see.
-template <int NP>
+//
+// BP = true: the B operand of EVERY task of the launch is a weight matrix whose bf16 pieces already exist in memory
+// ("planes", ft_planes.hip: [row][16-k chunk][hi | mid | lo][16 k in this kernel's LDS order], 96 B per row and chunk,
+// written once per step by the split definition above, so the products are bit-identical).  A thread then stages its
+// half of a B row with three 16-B loads (one for NP = 1: rn(x) IS the hi piece) and three ds_write_b128 -- no VALU -- where
+// every one of the M / 128 row tiles of the launch used to split the same weights again.  T.B points at the planes of the
+// task's first row / k chunk; row and tap strides follow from ldb and b_tap_stride.
+template <int NP, bool BP>
 __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch batch) {
   constexpr int TM = 2, TN = 2, BM = 128, BN = 128, SK = 16;
   constexpr int RW = NP == 3 ? 48 : 24;            // row stride, bf16 elements
@@ -389,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   bool a_ok;
   unsigned a_voff, vb, vbad0, vbad1;                 // bit 31 of a voffset = out of range = the load returns zeros
   unsigned va0, va1, vb0, vb1;                       // the voffsets of the stage under the cursor (two 16-B loads per row)
+  long btapb = 0;                                    // BP: bytes between the planes of consecutive taps
   bool ktail;                                        // K is not a multiple of the stage depth: the last chunk is masked
   const float* tapA;                                 // descriptor bases per (task, tap); the k position of a stage goes
   const float* tapB;                                 // into soffset
@@ -398,8 +395,10 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   auto mask_tail = [&]() {
     va0 |= vbad0;
     va1 |= vbad1;
-    vb0 |= vbad0;
-    vb1 |= vbad1;
+    if constexpr (!BP) {                             // planes are zero-filled up to the next multiple of 16 k
+      vb0 |= vbad0;
+      vb1 |= vbad1;
+    }
   };
   auto set_tap = [&]() {
     const int shift = shift0 + l_tap * sstep;
@@ -410,7 +409,8 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     vb1 = vb + 32u;
     if (ktail && kch == 1) mask_tail();
     tapA = a_base + (long)shift * atst * lda;
-    tapB = b_base + (long)l_tap * btap;
+    if constexpr (BP) tapB = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b_base) + (long)l_tap * btapb);
+    else tapB = b_base + (long)l_tap * btap;
   };
   auto setup = [&](const FtGemmTask& S, const float* SA, const float* SB) {
     tK = S.K;
@@ -434,8 +434,15 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     const int b = m / Tlog;
     a_t = m - b * Tlog;
     a_voff = (unsigned)((((long)b * abst + (long)a_t * atst) - row0) * lda * 4) + 16u * h;
-    b_base = SB + (long)n0 * S.ldb;
-    vb = n0 + rr < tN ? (unsigned)((long)rr * S.ldb * 4) + 16u * h : OOB;
+    if constexpr (BP) {
+      const long rowb = (long)((S.ldb + 15) / 16) * 96;                       // bytes of one planes row
+      b_base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(SB) + (long)n0 * rowb);
+      vb = n0 + rr < tN ? (unsigned)((long)rr * rowb) + 16u * h : OOB;
+      btapb = (S.b_tap_stride / S.ldb) * rowb;
+    } else {
+      b_base = SB + (long)n0 * S.ldb;
+      vb = n0 + rr < tN ? (unsigned)((long)rr * S.ldb * 4) + 16u * h : OOB;
+    }
     const int kl = (kch - 1) * SK;                   // only the last k chunk of a tap can reach past K
     ktail = tK % SK != 0;
     vbad0 = kl + 4 * h < tK ? 0u : OOB;
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   for (int i = 0; i < nchain; ++i) nch += batch.t[i].taps * ((batch.t[i].K + SK - 1) / SK);
   if (nchain == 1) nch = taps * kch;
 
-  struct Regs { u32x4 a0, a1, b0, b1; };
+  struct Regs { u32x4 a0, a1, b0, b1, b2; };
   // issue the four loads of the stage under the cursor.  No branch in here (the loads, the split of the older register
   // set and the MFMAs share one scheduling region, and the compiler's vmcnt counting stops at a branch).  A row outside
   // the tap's time window / the tile's M, N range or a k beyond K has bit 31 set in its voffset: out of range for the
@@ -466,8 +473,17 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(l_kc * SK * 4);
     R.a0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va0, soff, 0);
     R.a1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va1, soff, 0);
-    R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0, soff, 0);
-    R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb1, soff, 0);
+    if constexpr (BP) {
+      const unsigned soffb = (unsigned)__builtin_amdgcn_readfirstlane(l_kc * 96);
+      R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0, soffb, 0);                   // hi
+      if constexpr (NP == 3) {
+        R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb1, soffb, 0);                 // mid (vb + 32)
+        R.b2 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0 + 64u, soffb, 0);           // lo
+      }
+    } else {
+      R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0, soff, 0);
+      R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb1, soff, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);              // keep the requests at the top of the iteration (hipcc sinks them to
   };                                                // the bottom otherwise: zero prefetch distance)
   auto advance = [&]() {
@@ -502,7 +518,16 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   };
   auto store_stage = [&](const Regs& R, unsigned short* buf) {
     put8(buf + rr * RW + 8 * h, R.a0, R.a1);
-    put8(buf + (BM + rr) * RW + 8 * h, R.b0, R.b1);
+    if constexpr (BP) {
+      unsigned short* row = buf + (BM + rr) * RW + 8 * h;
+      *reinterpret_cast<u32x4*>(row) = R.b0;
+      if constexpr (NP == 3) {
+        *reinterpret_cast<u32x4*>(row + 16) = R.b1;
+        *reinterpret_cast<u32x4*>(row + 32) = R.b2;
+      }
+    } else {
+      put8(buf + (BM + rr) * RW + 8 * h, R.b0, R.b1);
+    }
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -524,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
 #pragma unroll
     for (int i = 0; i < TM * TN * (NP == 3 ? 6 : 1); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 5 : 8, 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? (BP ? 3 : 5) : (BP ? 4 : 8), 0);   // VALU
     }
   };
   // TWO fragment sets: the fragments of stage c+1 are read during the MFMAs of stage c (from the buffer the barrier at
@@ -873,8 +898,29 @@ int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStr
     span_ok = span_ok && ts >= 0 && bs >= 0 && rows * t.lda * 4 < (1L << 31) && 128L * t.ldb * 4 < (1L << 31);
   }
   if (big && pipelined && span_ok) {
-    if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1>), grid, dim3(256), 0, stream, batch);
-    else hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3>), grid, dim3(256), 0, stream, batch);
+    // weights whose bf16 pieces were prepared this step (ft_planes.hip): if EVERY task's B operand has them, the launch
+    // stages B without splitting (BP = true).  Same bits either way.
+    FtGemmBatch pb = batch;
+    bool planes = true;
+    const int nt = batch.t[0].nz > 1 ? 1 : ntask;
+    for (int i = 0; i < nt && i < FT_MAX_TASKS && planes; ++i) {
+      FtGemmTask& t = pb.t[i];
+      const long rows_per_tap = t.ldb > 0 ? t.b_tap_stride / t.ldb : 0;
+      planes = t.nz <= 1 && t.ldb > 0 && (t.taps <= 1 || (t.b_tap_stride > 0 && t.b_tap_stride % t.ldb == 0)) &&
+               128L * ((t.ldb + 15) / 16) * 96 < (1L << 31);
+      if (!planes) break;
+      const void* p = ft_planes_lookup(t.B, t.ldb, (long)(t.taps - 1) * rows_per_tap + t.N);
+      planes = p != nullptr;
+      t.B = static_cast<const float*>(p);
+    }
+    if (planes) {
+      if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1, true>), grid, dim3(256), 0, stream, pb);
+      else hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3, true>), grid, dim3(256), 0, stream, pb);
+    } else if (bf16) {
+      hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1, false>), grid, dim3(256), 0, stream, batch);
+    } else {
+      hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3, false>), grid, dim3(256), 0, stream, batch);
+    }
   } else if (big) {
     if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 1>), grid, dim3(256), 0, stream, batch);
     else hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 3>), grid, dim3(256), 0, stream, batch);

@@ -263,6 +263,7 @@ class TrainStep:
         finally:
             ops.set_grad_sink(None)
             H.pack_cache = None
+            packs.release()
             H.set_gemm_precision(old_precision)
         cur = torch.cuda.current_stream()
         cur.wait_stream(self.wgrad_stream)

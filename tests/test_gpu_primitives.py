@@ -116,6 +116,7 @@ def test_pack_weights_one_launch(H):
         assert torch.equal(H.transpose2d(other), other.t().contiguous())      # miss -> packed on the fly
     finally:
         H.pack_cache = None
+        cache.release()
 
 
 def test_linear_multi(H):
@@ -375,3 +376,107 @@ def test_bank_bn_pool_fused_equals_three_passes(H, B, T, Cin, C, K):
     ref = torch.nn.functional.max_pool1d(zc, kernel_size=2, stride=1, padding=1)[:, :, :T]
     assert rel_err(res[True][0], ref.transpose(1, 2).detach()) < 2e-5
     # (the gradients' parity with the reference is pinned end to end: tests/test_gpu_model.py's golden train steps)
+
+
+def _planes_counters():
+    import ctypes
+    from forwardtacotron_amd import _lib
+    v = [ctypes.c_long(0) for _ in range(4)]
+    _lib.call('ft_planes_counters', *[ctypes.byref(x) for x in v])
+    return [x.value for x in v]         # hits, misses, registered, wanted
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_presplit_weight_planes_give_the_same_bits(H, mode):
+    """ft_planes_*: the 128x128 NT GEMM fed with weights split ONCE per step (planes) must give the same bits as the
+    same launch splitting in the kernel -- Linear forward (raw weight), its data gradient (transposed weight), a k-tap
+    conv (tap-major pack, K = 88: a zero-filled chunk tail), a conv bank (members at row offsets inside one pack) and the
+    bank's chained data gradient -- in the fp32-exact and the bf16 mode.  A matrix is only split once a launch has asked
+    for it; after release() nothing is served from planes.  (The mechanism is off by default: measured slower, ft_planes.hip.)"""
+    g = torch.Generator().manual_seed(5)
+    Bn, T = 32, 400                                  # 12 800 rows = 100 row tiles: every launch below takes the 128x128 kernel
+    w = dev(torch.randn(256, 256, generator=g) * 0.1)
+    cw = dev(torch.randn(256, 88, 5, generator=g) * 0.2)
+    bank = [dev(torch.randn(128, 256, k, generator=g) * 0.1) for k in range(1, 4)]
+    x = dev(torch.randn(Bn, T, 256, generator=g))
+    x88 = dev(torch.randn(Bn, T, 88, generator=g))
+    dy = dev(torch.randn(Bn, T, 256, generator=g))
+    dyb = dev(torch.randn(Bn, T + 1, 3 * 128, generator=g))
+    from forwardtacotron_amd import _lib
+    old = H.set_gemm_precision(mode)
+    was_on = _lib.query('ft_planes_enable', 1)       # off by default (measured slower): on for this test
+    cache = H.PackCache([w], [cw], [bank], w.device)
+
+    def run():
+        wp = H.conv_pack_weight(cw)
+        return [H.linear_fwd(x, w), H.linear_bwd_data(dy, w), H.conv1d_fwd(x88, wp, True),
+                H.conv_bank_fwd(x, H.bank_packs(bank, False), 3, 128, True, T + 1),
+                H.conv_bank_bwd_data(dyb, H.bank_packs(bank, False), 3, 128, 256, T, ws=bank)]
+
+    try:
+        ref = run()                                  # no cache: packs on the fly, split in the kernel
+        H.pack_cache = cache
+        cache.refresh()
+        h0, m0, reg, _ = _planes_counters()
+        assert reg >= 6
+        first = run()                                # registered but never asked for: not split yet -> misses
+        h1, m1, _, wanted = _planes_counters()
+        assert h1 == h0 and m1 > m0 and wanted >= 4
+        cache.refresh()                              # splits what was asked for
+        second = run()
+        h2, m2, _, _ = _planes_counters()
+        assert h2 - h1 >= 5 and m2 == m1             # every launch above served from planes (the bank: one per member)
+        torch.cuda.synchronize()
+        for a, b, c in zip(ref, first, second):
+            assert torch.equal(a, b) and torch.equal(a, c)
+        cache.release()
+        third = run()
+        h3, _, _, _ = _planes_counters()
+        assert h3 == h2
+        for a, b in zip(ref, third):
+            assert torch.equal(a, b)
+    finally:
+        H.pack_cache = None
+        cache.release()
+        H.set_gemm_precision(old)
+        _lib.query('ft_planes_enable', was_on)
+
+
+def test_non_recurrent_entry_points_are_graph_capturable(H):
+    """include/fwdtaco_hip.h, conventions: an entry point only enqueues work on the stream it is given (no sync, no
+    allocation), so a chain of them can be captured in a hipGraph -- everything except the persistent recurrences, whose
+    admission bookkeeping records and queries events on the host.  A token-side chain (embedding -> k-tap conv + ReLU ->
+    Linear -> LengthRegulator scan + expand) is captured once with torch.cuda.graph and replayed on new inputs: the
+    replays must equal the eager launches bit for bit."""
+    g = torch.Generator().manual_seed(9)
+    V, C, B, Tx, Tm = 40, 64, 4, 24, 100
+    emb = dev(torch.randn(V, C, generator=g))
+    cw = dev(torch.randn(96, C, 5, generator=g) * 0.2)
+    lw = dev(torch.randn(48, 96, generator=g) * 0.2)
+    wp = H.conv_pack_weight(cw)
+    idx = dev(torch.randint(1, V, (B, Tx), generator=g))
+    dur = dev(torch.randint(0, 6, (B, Tx), generator=g).float())
+
+    def chain(idx_, dur_):
+        x = H.embedding_fwd(idx_, emb)
+        y = H.linear_fwd(H.conv1d_fwd(x, wp, True), lw)
+        cum, total = H.lr_scan(dur_)
+        return H.lr_expand(y, cum, Tm), total
+
+    s_idx, s_dur = idx.clone(), dur.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chain(s_idx, s_dur)                          # warm-up outside the capture (workspaces, lazy module loads)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, total = chain(s_idx, s_dur)
+    for seed in (1, 2):
+        g2 = torch.Generator().manual_seed(seed)
+        s_idx.copy_(dev(torch.randint(1, V, (B, Tx), generator=g2)))
+        s_dur.copy_(dev(torch.randint(0, 6, (B, Tx), generator=g2).float()))
+        graph.replay()
+        want, want_total = chain(s_idx.clone(), s_dur.clone())
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and torch.equal(total, want_total)
