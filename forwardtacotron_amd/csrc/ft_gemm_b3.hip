@@ -866,11 +866,298 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3_kernel(FtGemmTNTask T, f
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The 128x128 TN kernel, software-pipelined ("tn_b3p") -- the structure of ft_gemm_rows_b3p_kernel applied to the weight
+// gradients: stages of 16 contraction rows (8 pair-rows), TWO LDS buffers (2 x 25.5 KB, two workgroups per CU) and TWO
+// fragment sets, one barrier per stage, the split + ds_write of stage c+2 and the row bookkeeping of stage c+3 issued in
+// the shadow of stage c's 24 MFMAs.  Operands arrive by buffer loads whose out-of-range voffset returns zeros: a row past
+// the split's end, outside the tap's time window or a column quad beyond M / N just carries bit 31 -- the two-barrier
+// kernel above wraps each of its 8 loads per stage in an exec-masked block with a `while` behind it.  A thread stages
+// rows (2 pr, 2 pr + 1) of 4 adjacent columns of A and of B; it tracks t = row % Tlog of its two rows and their byte
+// offsets incrementally (a stage advances by 16 rows: at most one wrap into the next item, hence Tlog >= 16), all with
+// selects.  Same arithmetic in the same order as the kernel above (16 rows per MFMA step, six terms small-first): the
+// slabs are bit-identical.  Requires amap.Tlog == bmap.Tlog >= 16 and operands addressable with 31-bit byte offsets from
+// their base (checked by the launcher, which otherwise keeps the two-barrier kernel).
+template <int NP>
+__global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3p_kernel(FtGemmTNTask T, float* slab, int S, int rows_per_split) {
+  constexpr int TM = 2, TN = 2, BM = 128, BN = 128, SK = 16;
+  constexpr int RW = BM + 8;                         // pair-row stride in 32-bit words (A and B tiles alike)
+  constexpr int PL = 8 * RW;                         // plane stride: 8 pair-rows per stage
+  constexpr int OPW = NP * PL;                       // one operand tile of one stage
+  constexpr int BUF = 2 * OPW;
+  __shared__ __attribute__((aligned(16))) unsigned smem[2 * BUF];
+
+  const FtTnWho who = ft_tn_who(T, S, BM);
+  const int m0 = who.mtile * BM, n0 = blockIdx.y * BN;
+  const int zts = who.zts, s = who.s;
+  const int zi = zts / T.taps, tap = zts - zi * T.taps;
+  const float* TA = T.A;
+  const float* TB = T.B;
+  if (T.nz > 1) {
+    const int z0 = zi / T.nz1, z1 = zi - z0 * T.nz1;
+    TA += z0 * T.sA0 + z1 * T.sA1;
+    TB += z0 * T.sB0 + z1 * T.sB1;
+  }
+  const int r_begin = s * rows_per_split;
+  const int r_end = min(T.R, r_begin + rows_per_split);
+  const int tid = threadIdx.x;
+  const int tM = T.M, tN = T.N;
+  const int Tlog = T.amap.Tlog;
+  const int ashift = T.amap.shift0 + tap * T.amap.shift_step;
+  int bshift = T.bmap.shift0 + tap * T.bmap.shift_step;
+  int aTvalid = T.amap.Tvalid;
+  const int bTvalid = T.bmap.Tvalid;
+  if (who.kk > 0) {                           // conv-bank mode (FtGemmTNTask): member of this tile
+    bshift = tap - who.kk / 2;
+    if (who.kk & 1) aTvalid = T.bankTodd;
+  }
+  constexpr unsigned OOB = 0x80000000u, NREC = 0x7fffffffu;
+  const int mq = tid & 31, pr = tid >> 5;            // column quad, pair-row of the stage
+  const bool am_ok = m0 + 4 * mq < tM, bn_ok = n0 + 4 * mq < tN;
+  // per staged row i = 0, 1: t within its item, byte offsets of (row, this thread's column quad) in A and B
+  int t_[2];
+  unsigned oa[2], ob[2];
+  const unsigned a_step = (unsigned)(16L * T.amap.tstride * T.lda * 4);
+  const unsigned a_wrap = (unsigned)(((long)T.amap.bstride + (16L - Tlog) * T.amap.tstride) * T.lda * 4);
+  const unsigned b_step = (unsigned)(16L * T.bmap.tstride * T.ldb * 4);
+  const unsigned b_wrap = (unsigned)(((long)T.bmap.bstride + (16L - Tlog) * T.bmap.tstride) * T.ldb * 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = r_begin + 2 * pr + i;
+    const int b = r / Tlog;
+    t_[i] = r - b * Tlog;
+    oa[i] = (unsigned)(((long)b * T.amap.bstride + (long)(t_[i] + ashift) * T.amap.tstride) * T.lda * 4) + 16u * mq;
+    ob[i] = (unsigned)(((long)b * T.bmap.bstride + (long)(t_[i] + bshift) * T.bmap.tstride) * T.ldb * 4) + 16u * mq;
+  }
+  int rows_left = r_end - r_begin - 2 * pr;          // rows of this thread's pair still inside the split (> 0: row 0 ok)
+  unsigned va[2], vb[2];
+  auto voffsets = [&]() {                            // validity of the rows under the cursor -> bit 31
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool in = rows_left > i;
+      const bool wa = (unsigned)(t_[i] + ashift) < (unsigned)aTvalid;
+      const bool wb = (unsigned)(t_[i] + bshift) < (unsigned)bTvalid;
+      va[i] = (in & wa & am_ok) ? oa[i] : OOB;
+      vb[i] = (in & wb & bn_ok) ? ob[i] : OOB;
+    }
+  };
+  auto advance = [&]() {                             // the cursor moves 16 rows on
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t1 = t_[i] + SK;
+      const bool w = t1 >= Tlog;
+      t_[i] = w ? t1 - Tlog : t1;
+      oa[i] += w ? a_wrap : a_step;
+      ob[i] += w ? b_wrap : b_step;
+    }
+    rows_left -= SK;
+    voffsets();
+  };
+  voffsets();
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(TA + m0), 0, NREC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(TB + n0), 0, NREC, 0x00020000);
+  struct Regs { u32x4 a0, a1, b0, b1; };             // rows (even, odd) of A, of B
+  auto load_stage = [&](Regs& R) {
+    R.a0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va[0], 0, 0);
+    R.a1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va[1], 0, 0);
+    R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb[0], 0, 0);
+    R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb[1], 0, 0);
+    __builtin_amdgcn_sched_barrier(0);              // keep the requests at the top of the iteration
+  };
+  // rows (even, odd) of 4 columns -> NP 16-B pieces of pair-packed bf16 (word = odd row << 16 | even row)
+  auto put_pair = [&](unsigned* dst, const u32x4& ev, const u32x4& od) {
+    const float4 e = __builtin_bit_cast(float4, ev), o = __builtin_bit_cast(float4, od);
+    if constexpr (NP == 1) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(rn_pack(e.x, o.x), rn_pack(e.y, o.y), rn_pack(e.z, o.z), rn_pack(e.w, o.w));
+    } else {
+      unsigned hi[4], mid[4], lo[4];
+      split_pair(e.x, o.x, hi[0], mid[0], lo[0]);
+      split_pair(e.y, o.y, hi[1], mid[1], lo[1]);
+      split_pair(e.z, o.z, hi[2], mid[2], lo[2]);
+      split_pair(e.w, o.w, hi[3], mid[3], lo[3]);
+      *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      *reinterpret_cast<uint4*>(dst + PL) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+      *reinterpret_cast<uint4*>(dst + 2 * PL) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+  };
+  auto store_stage = [&](const Regs& R, unsigned* buf) {
+    put_pair(buf + pr * RW + 4 * mq, R.a0, R.a1);
+    put_pair(buf + OPW + pr * RW + 4 * mq, R.b0, R.b1);
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment: pair-rows 4 half + {0..3} (= rows 8 half .. 8 half + 7 of the stage), column (tile column) + l31
+  const int aoff = 4 * half * RW + wm * 64 + l31;
+  const int boff = OPW + 4 * half * RW + wn * 64 + l31;
+  bf16x8 fa[TM][NP], fb[TN][NP], ga[TM][NP], gb[TN][NP];
+  auto read_into = [&](bf16x8 (&xa)[TM][NP], bf16x8 (&xb)[TN][NP], const unsigned* buf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        const unsigned* q = buf + aoff + pl * PL + 32 * i;
+        xa[i][pl] = __builtin_bit_cast(bf16x8, make_uint4(q[0], q[RW], q[2 * RW], q[3 * RW]));
+      }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        const unsigned* q = buf + boff + pl * PL + 32 * j;
+        xb[j][pl] = __builtin_bit_cast(bf16x8, make_uint4(q[0], q[RW], q[2 * RW], q[3 * RW]));
+      }
+  };
+  // per accumulator the six terms small-first, as in the two-barrier kernel (bit-identical slabs); term-major so that
+  // consecutive MFMAs go to different accumulators
+  auto mfma_on = [&](bf16x8 (&xa)[TM][NP], bf16x8 (&xb)[TN][NP]) {
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int term = 0; term < (NP == 3 ? 6 : 1); ++term)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int pa = NP == 3 ? PA_[term] : 0, pb = NP == 3 ? PB_[term] : 0;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i][pa], xb[j][pb], acc[i][j], 0, 0, 0);
+        }
+  };
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM * TN * (NP == 3 ? 6 : 1); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, NP == 3 ? 2 : 4, 0);      // DS reads of the next stage's fragments
+      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 6 : 12, 0);     // VALU: split + row bookkeeping
+    }
+  };
+
+  const int nch = r_begin < r_end ? (r_end - r_begin + SK - 1) / SK : 0;
+  if (nch > 0) {
+    unsigned* const buf0 = smem;
+    unsigned* const buf1 = smem + BUF;
+    Regs R0, R1;
+    load_stage(R0);
+    advance();
+    if (nch > 1) {
+      load_stage(R1);
+      advance();
+    }
+    store_stage(R0, buf0);                           // stage 0
+    __syncthreads();
+    if (nch > 2) {
+      load_stage(R0);                                // stage 2
+      advance();
+    }
+    read_into(fa, fb, buf0);
+    if (nch > 1) store_stage(R1, buf1);              // stage 1
+    __syncthreads();
+    // iteration c (even): fragments of stage c in (fa, fb), stage c+1 in buf1, stage c+2 in R0 (in flight), cursor at c+3
+    int c = 0;
+    for (; c + 4 < nch; c += 2) {
+      load_stage(R1);                                // c+3
+      advance();
+      read_into(ga, gb, buf1);
+      store_stage(R0, buf0);                         // c+2
+      mfma_on(fa, fb);
+      interleave();
+      __syncthreads();
+      load_stage(R0);                                // c+4
+      advance();
+      read_into(fa, fb, buf0);
+      store_stage(R1, buf1);                         // c+3
+      mfma_on(ga, gb);
+      interleave();
+      __syncthreads();
+    }
+    const int left = nch - c;                        // 1 .. 4 stages, same state as at the top of an iteration
+    if (left == 4) {
+      load_stage(R1);                                // c+3
+      read_into(ga, gb, buf1);
+      store_stage(R0, buf0);                         // c+2
+      mfma_on(fa, fb);
+      __syncthreads();
+      read_into(fa, fb, buf0);
+      store_stage(R1, buf1);                         // c+3
+      mfma_on(ga, gb);
+      __syncthreads();
+      read_into(ga, gb, buf1);
+      mfma_on(fa, fb);
+      mfma_on(ga, gb);
+    } else if (left == 3) {
+      read_into(ga, gb, buf1);
+      store_stage(R0, buf0);                         // c+2
+      mfma_on(fa, fb);
+      __syncthreads();
+      read_into(fa, fb, buf0);
+      mfma_on(ga, gb);
+      mfma_on(fa, fb);
+    } else if (left == 2) {
+      read_into(ga, gb, buf1);
+      mfma_on(fa, fb);
+      mfma_on(ga, gb);
+    } else {
+      mfma_on(fa, fb);
+    }
+  }
+  float* out = slab + ((long)zts * S + s) * tM * tN;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + l31;
+      if (col >= tN) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row < tM) out[(long)row * tN + col] = acc[i][j][e];
+      }
+    }
+}
+
 }  // namespace
 
 int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
                          hipStream_t stream) {
   const bool bf16 = ft_gemm_precision() == 1;
+  static const bool pipelined = [] {                 // FT_GEMM_TN_PIPE=0: the two-barrier 128x128 kernel (A/B knob)
+    const char* e = getenv("FT_GEMM_TN_PIPE");
+    return !(e && e[0] == '0');
+  }();
+  // short splits (few stages per workgroup) do not amortise the deeper prologue: 256 x 256 x 26912 at 224 rows per split
+  // ran 54 -> 59 us on the pipelined kernel, the shapes with >= 1000 rows per split gain 17-25 % (lab/tn_pipe_ab.py)
+  if (tm == 2 && pipelined && rows_per_split % 16 == 0 && rows_per_split >= 512 && t.amap.Tlog == t.bmap.Tlog &&
+      t.amap.Tlog >= 16) {
+    // the pipelined kernel addresses rows with 31-bit byte offsets from the operand's base (buffer loads) and walks them
+    // with non-negative strides
+    auto span_ok = [](const FtRowMap& m, long R, long ld, int taps) {
+      if (m.bstride < 0 || m.tstride < 0) return false;
+      const long items = (R + m.Tlog - 1) / m.Tlog;
+      long lo = m.shift0 < 0 ? m.shift0 : 0, hi = m.shift0 > 0 ? m.shift0 : 0;
+      const long last = (long)m.shift0 + (long)(taps - 1) * m.shift_step;
+      lo = last < lo ? last : lo;
+      hi = last > hi ? last : hi;
+      lo -= taps;                                    // conv-bank mode: shifts tap - kk/2 within [-taps, taps]
+      hi += taps;
+      const long maxrow = (items + 1) * m.bstride + (m.Tlog + 16 + hi) * m.tstride;
+      (void)lo;                                      // rows below the base only occur masked (t + shift < 0)
+      return (maxrow + 1) * ld * 4 + 1024 < (1L << 31);
+    };
+    if (span_ok(t.amap, t.R, t.lda, t.taps) && span_ok(t.bmap, t.R, t.ldb, t.taps)) {
+      if (bf16) hipLaunchKernelGGL((ft_gemm_tn_b3p_kernel<1>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+      else hipLaunchKernelGGL((ft_gemm_tn_b3p_kernel<3>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+      return FT_OK;
+    }
+  }
   if (tm == 2) {
     if (bf16) hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<2, 2, 1>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
     else hipLaunchKernelGGL((ft_gemm_tn_b3_kernel<2, 2, 3>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);

@@ -1,4 +1,4 @@
-"""weight-gradient (TN) GEMMs in isolation: FT_GEMM_TN_WALK=0 vs 1 (one process per setting)."""
+"""weight-gradient (TN) GEMMs in isolation: FT_GEMM_TN_PIPE=0 (two-barrier kernel) vs 1 (software-pipelined) (one process per setting)."""
 import os, subprocess, sys
 sys.path.insert(0, '.')
 def child():
@@ -21,5 +21,5 @@ if __name__ == '__main__':
     if len(sys.argv) > 1: child()
     else:
         for v in ('0', '1', '0', '1'):
-            print('=== FT_GEMM_TN_WALK=' + v, flush=True)
-            subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, FT_GEMM_TN_WALK=v), check=True)
+            print('=== FT_GEMM_TN_PIPE=' + v, flush=True)
+            subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, FT_GEMM_TN_PIPE=v), check=True)
