@@ -1032,6 +1032,8 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3p_kernel(FtGemmTNTask T, 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[i][pa], xb[j][pb], acc[i][j], 0, 0, 0);
         }
   };
+  // measured alternatives (LSTM shapes, same box): the compiler's own schedule -4 %, all fragment reads in front of the
+  // MFMAs (the NT kernel's pattern) -3 %, reads and VALU in two alternating halves per MFMA: the same
   auto interleave = [&]() {
 #pragma unroll
     for (int i = 0; i < TM * TN * (NP == 3 ? 6 : 1); ++i) {
