@@ -1128,6 +1128,9 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_tn_b3p_kernel(FtGemmTNTask T, 
 
 }  // namespace
 
+static long g_tn_pipelined = 0;
+extern "C" int ft_gemm_tn_pipelined_launches(void) { return (int)g_tn_pipelined; }
+
 int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
                          hipStream_t stream) {
   const bool bf16 = ft_gemm_precision() == 1;
@@ -1157,6 +1160,7 @@ int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per
     if (span_ok(t.amap, t.R, t.lda, t.taps) && span_ok(t.bmap, t.R, t.ldb, t.taps)) {
       if (bf16) hipLaunchKernelGGL((ft_gemm_tn_b3p_kernel<1>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
       else hipLaunchKernelGGL((ft_gemm_tn_b3p_kernel<3>), grid, dim3(256), 0, stream, t, slab, S, rows_per_split);
+      ++g_tn_pipelined;
       return FT_OK;
     }
   }

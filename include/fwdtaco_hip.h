@@ -39,6 +39,9 @@ int ft_device_info(int* cu_count, int* is_gfx950);
  *     data gradients, every weight gradient, attention Q K^T); the rest (NN-form attention products, odd shapes) and all
  *     non-GEMM kernels (LayerNorm, softmax statistics, losses, optimizer, recurrences) stay fp32. */
 int ft_set_gemm_precision(int bf16);
+/* weight-gradient launches that took the software-pipelined 128x128 kernel since the library loaded (tests use it to
+ * prove which kernel they exercised; the choice never changes results: both kernels give the same bits) */
+int ft_gemm_tn_pipelined_launches(void);
 
 /* ---- nn.Linear (models/forward_tacotron.py:25,100,108 ; common_layers.py:31-32,83) ------------------ */
 /* Row layouts: the rows of an activation matrix are the (b,t) positions in batch-major order (row = b*T+t,

@@ -480,3 +480,77 @@ def test_non_recurrent_entry_points_are_graph_capturable(H):
         want, want_total = chain(s_idx.clone(), s_dur.clone())
         torch.cuda.synchronize()
         assert torch.equal(out, want) and torch.equal(total, want_total)
+
+
+def _tn_pipelined():
+    from forwardtacotron_amd import _lib
+    return _lib.query('ft_gemm_tn_pipelined_launches')
+
+
+@pytest.mark.parametrize('form', ['linear_tm_shift', 'conv_k5', 'bank', 'linear_bf16'])
+def test_weight_gradient_pipelined_kernel(H, form):
+    """ft_gemm_tn_b3p_kernel (the software-pipelined 128x128 weight-gradient kernel) only takes launches with >= 512
+    contraction rows per split, which the mid-size model tests do not reach: here every form it serves is run at a size
+    that does (the launch counter proves it) and compared with a float64 reference -- the LSTM W_hh form (time-major
+    dy, a one-step shift of the time-major x inside each item, T not a multiple of the 16-row stage), a 5-tap conv
+    (rows outside the tap's window at both ends of every item), the conv-bank mode (members with their own taps /
+    shifts / valid lengths in one launch) and the bf16 precision mode."""
+    from forwardtacotron_amd.hip import linear_bwd_weight_raw
+    g = torch.Generator().manual_seed(77)
+    n0 = _tn_pipelined()
+    if form in ('linear_tm_shift', 'linear_bf16'):
+        B, T, O, I = 16, 601, 1024, 512
+        dy = dev(torch.randn(T, B, O, generator=g))              # time-major, as the recurrences leave it
+        x = dev(torch.randn(T, B, I, generator=g))
+        old = H.set_gemm_precision('bf16' if form == 'linear_bf16' else 'fp32')
+        try:
+            for shift in (-1, 1):
+                xs = torch.zeros_like(x)
+                if shift == -1:
+                    xs[1:] = x[:-1]
+                else:
+                    xs[:-1] = x[1:]
+                ref = dy.reshape(-1, O).double().t() @ xs.reshape(-1, I).double()
+                dw = torch.empty(O, I, device='cuda')
+                linear_bwd_weight_raw(dy.data_ptr(), O, x.data_ptr(), I, dw, B * T, I, O, B=B, T=T, x_shift=shift,
+                                      dy_tm=True, x_tm=True)
+                assert rel_err(dw, ref) < (2e-2 if form == 'linear_bf16' else 2e-6), shift
+        finally:
+            H.set_gemm_precision(old)
+        assert _tn_pipelined() - n0 == 2
+    elif form == 'conv_k5':
+        B, T, Cin, Cout, k = 16, 501, 256, 512, 5
+        x = dev(torch.randn(B, T, Cin, generator=g))
+        dy = dev(torch.randn(B, T, Cout, generator=g))
+        dw = torch.empty(Cout, Cin, k, device='cuda')
+        H.conv1d_bwd_weight_raw(dy.data_ptr(), Cout, x, dw, T, T)
+        for j in range(k):                                        # dw[:, :, j] = sum_{b,t} dy[b,t,:]^T x[b,t+j-k//2,:]
+            sh = j - k // 2
+            xs = torch.zeros_like(x)
+            if sh < 0:
+                xs[:, -sh:] = x[:, :sh]
+            elif sh > 0:
+                xs[:, :-sh] = x[:, sh:]
+            else:
+                xs = x
+            ref = dy.reshape(-1, Cout).double().t() @ xs.reshape(-1, Cin).double()
+            assert rel_err(dw[:, :, j], ref) < 2e-6, j
+        assert _tn_pipelined() - n0 == 1
+    else:
+        B, T, Cin, C, K = 64, 2800, 128, 128, 3
+        x = dev(torch.randn(B, T, Cin, generator=g))
+        dy = dev(torch.randn(B, T + 1, K * C, generator=g))
+        dws = [torch.full((C, Cin, kk), float('nan'), device='cuda') for kk in range(1, K + 1)]
+        H.conv_bank_bwd_weight(dy, x, dws, C)
+        xp = torch.zeros(B, T + 4, Cin, device='cuda')            # x with two zero frames on either side
+        xp[:, 2:T + 2] = x
+        for i in range(K):
+            kk = i + 1
+            Tv = T + (1 if kk % 2 == 0 else 0)                    # rows of the bank buffer member kk really produced
+            dyk = dy[:, :Tv, i * C:(i + 1) * C].double()
+            for j in range(kk):                                   # y[t] = sum_j w[:, :, j] x[t + j - kk//2]
+                sh = j - kk // 2
+                xs = xp[:, 2 + sh:2 + sh + Tv].double()
+                ref = dyk.reshape(-1, C).t() @ xs.reshape(-1, Cin)
+                assert rel_err(dws[i][:, :, j], ref) < 3e-6, (kk, j)
+        assert _tn_pipelined() - n0 == 1
