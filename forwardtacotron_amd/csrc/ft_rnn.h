@@ -15,6 +15,9 @@ struct RnnFwdArgs {
   float* gates;           // optional [T,B,ND,4*H] saved activations (training)
   const long* lens;       // optional [B]
   int B, T, H, ND, s, vec;
+  // rows per time step of the buffers (the persistent forward can be launched on a SLICE of the batch: B rows starting
+  // at the pointers above, inside buffers whose time steps are Bld rows apart); the per-step kernels take Bld == B
+  int Bld;
 };
 
 struct RnnBwdArgs {

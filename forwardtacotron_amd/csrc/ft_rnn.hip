@@ -329,12 +329,38 @@ int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float
   RnnFwdArgs a;
   a.xp = xp; a.whh[0] = whh_f; a.whh[1] = whh_r; a.bhh[0] = bhh_f; a.bhh[1] = bhh_r;
   a.out = out; a.cst = cst; a.gates = gates; a.lens = lens;
-  a.B = B; a.T = T; a.H = H; a.ND = 2;
+  a.B = B; a.T = T; a.H = H; a.ND = 2; a.Bld = B;
   a.vec = (H % 4 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)whh_f % 16 == 0) && ((uintptr_t)whh_r % 16 == 0);
   const bool fast = a.vec && (H % 16 == 0);
   {
     const int rc = ft_rnn_fwd_persistent(G, a, ws, ws_bytes, stream);      // writes the zeros of finished items itself
     if (rc != -1) return rc;
+  }
+  // A batch too large for ONE persistent grid (all workgroups must be co-resident: the 512-wide LSTM fills the chip at 64
+  // rows) runs as several persistent launches over 64-row slices of the batch, one after the other -- batch rows are
+  // independent -- instead of T per-step launches: the long-form inference batch (128 items x 6093 frames) spent 137 of
+  // its 255 ms in 6093 per-step LSTM launches of 22 us each.
+  constexpr int SLICE = 64;
+  if (B > SLICE && a.vec && H % 16 == 0) {
+    auto slice = [&](int bo) {
+      RnnFwdArgs c = a;
+      const long ldo = (long)a.ND * H;
+      c.xp = a.xp + (long)bo * a.ND * G * H;
+      c.out = a.out + bo * ldo;
+      c.cst = a.cst ? a.cst + bo * ldo : nullptr;
+      c.gates = a.gates ? a.gates + (long)bo * a.ND * 4 * H : nullptr;
+      c.lens = a.lens ? a.lens + bo : nullptr;
+      c.B = B - bo < SLICE ? B - bo : SLICE;
+      return c;
+    };
+    int rc = ft_rnn_fwd_persistent(G, slice(0), ws, ws_bytes, stream);
+    if (rc != -1) {
+      for (int bo = SLICE; bo < B && rc == FT_OK; bo += SLICE) {
+        rc = ft_rnn_fwd_persistent(G, slice(bo), ws, ws_bytes, stream);
+        FT_REQUIRE(rc != -1, "rnn_fwd: a later batch slice was refused the persistent form the first one got");
+      }
+      return rc;
+    }
   }
   if (lens) {   // inactive positions must read as zeros
     (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * T * 2 * H, stream);

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
   for (int g = 0; g < G; ++g) xg[g] = 0.f;
   if (cthr && 0 < L) {
     const int ct = d == 0 ? 0 : L - 1;
-    const float* xr = a.xp + ((long)ct * a.B + cb) * ldx + (long)d * G * H + cun;
+    const float* xr = a.xp + ((long)ct * a.Bld + cb) * ldx + (long)d * G * H + cun;
 #pragma unroll
     for (int g = 0; g < G; ++g) xg[g] = xr[(long)g * H];
   }
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
     auto request_xn = [&]() {
       if (cthr && s + 1 < L) {
         const int cn = d == 0 ? s + 1 : L - 2 - s;
-        const float* xr = a.xp + ((long)cn * a.B + cb) * ldx + (long)d * G * H + cun;
+        const float* xr = a.xp + ((long)cn * a.Bld + cb) * ldx + (long)d * G * H + cun;
 #pragma unroll
         for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
       }
@@ -527,15 +527,15 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
         __hip_atomic_fetch_add(mycnt + (chunk % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (cact) {                                          // the step's outputs proper: off the recurrence's path
-      const long o = ((long)ct * a.B + cb) * ldo + (long)d * H + cun;
+      const long o = ((long)ct * a.Bld + cb) * ldo + (long)d * H + cun;
       a.out[o] = hnew;
       if (G == 4) a.cst[o] = cnew;
       if (a.gates) {
-        float* gs = a.gates + (((long)ct * a.B + cb) * a.ND + d) * 4 * H + cun;
+        float* gs = a.gates + (((long)ct * a.Bld + cb) * a.ND + d) * 4 * H + cun;
         gs[0] = sg[0]; gs[H] = sg[1]; gs[2 * H] = sg[2]; gs[3 * H] = sg[3];
       }
     } else if (cthr) {                                   // finished item: positions t >= L read as zeros (t = s, both directions)
-      const long o = ((long)s * a.B + cb) * ldo + (long)d * H + cun;
+      const long o = ((long)s * a.Bld + cb) * ldo + (long)d * H + cun;
       a.out[o] = 0.f;
       if (G == 4) a.cst[o] = 0.f;
     }

@@ -161,3 +161,39 @@ def test_reduce_scatter_backward_equals_all_gather(G, B, T, Hh, monkeypatch):
     for a, b in zip(res['2'], res['0']):
         assert torch.isfinite(a).all()
         assert maxdiff(a, b) < 2e-6 * max(1.0, float(b.abs().max()))
+
+
+def test_lstm_forward_sliced_over_a_batch_too_large_for_one_persistent_grid():
+    """The 512-wide LSTM fills the chip with 64 batch rows; a larger batch (long-form inference: 128 items) used to fall
+    back to T per-step launches.  It now runs as persistent launches over 64-row slices of the batch (rows are
+    independent; the buffers' time steps stay B rows apart: RnnFwdArgs.Bld).  B = 80 -> slices of 64 and 16 rows: the
+    result must match the per-step kernels row for row (incl. packed lengths: zeros beyond an item's length), and the
+    launch counters must show two persistent launches and no per-step fallback for the call."""
+    from forwardtacotron_amd import hip as H
+    g = torch.Generator().manual_seed(123)
+    B, T, Hh = 80, 9, 512
+    xp = (torch.randn(T, B, 8 * Hh, generator=g) * 0.5).cuda()
+    whh = [(torch.randn(4 * Hh, Hh, generator=g) * 0.05).cuda() for _ in range(2)]
+    bhh = [(torch.randn(4 * Hh, generator=g) * 0.1).cuda() for _ in range(2)]
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[3] = T
+    lens = lens.cuda()
+    res = {}
+    for mode in (1, 0):
+        old = _set_persistent(mode)
+        try:
+            c0 = H.rnn_counters()
+            raw, cst, gates = H.lstm_fwd(xp, whh[0], whh[1], bhh[0], bhh[1], lens, Hh, True)
+            torch.cuda.synchronize()
+            H.check_rnn_status()
+            c1 = H.rnn_counters()
+            res[mode] = (raw.cpu(), cst.cpu(), gates.cpu(), c1[0] - c0[0])
+        finally:
+            _set_persistent(old)
+    assert res[1][3] == 2 and res[0][3] == 0, 'expected two persistent slice launches'
+    assert maxdiff(res[1][0], res[0][0]) < 1e-5 and maxdiff(res[1][1], res[0][1]) < 2e-5
+    tmask = torch.arange(T)[:, None] >= lens.cpu()[None, :]                    # [T,B] positions beyond an item's length
+    assert float(res[1][0][tmask].abs().max()) == 0.0
+    act = ~tmask
+    # saved activations only exist at active positions
+    assert maxdiff(res[1][2][act], res[0][2][act]) < 1e-5
