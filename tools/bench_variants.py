@@ -86,6 +86,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    c0 = hip.rnn_counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -106,6 +107,10 @@ def main():
             'frac_of_f32_mfma_peak': round(fl / dt / 157.3e12, 4),
             'frac_of_bf16_dense_peak': round(fl / dt / 2500e12, 4), 'dtype': 'f32' if args.dtype == 'fp32' else 'bf16',
             'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    c1 = hip.rnn_counters()
+    # recurrence launches per step in the timed region: persistent ones / launches refused the persistent form (each
+    # refusal = T per-step launches, unless the forward then ran as persistent launches over batch slices)
+    line['rnn_launches_per_step'] = {'persistent': (c1[0] - c0[0]) / args.steps, 'refused': (c1[1] - c0[1]) / args.steps}
     if args.mode == 'train':
         line['loss'] = round(float(out['loss']), 5)
     print(json.dumps(line), flush=True)
