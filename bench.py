@@ -134,7 +134,7 @@ def family_rooflines(recs, steps, batch, step_ms, lr_iso_ms=None):
         acc['dep_steps'] += info['T']
         acc['launches'] += 1
     out = []
-    for tag, acc in (('trunk (prenet GRU-256, LSTM-512, postnet GRU-128; the step\'s critical stream)', trunk),
+    for tag, acc in (('trunk (prenet GRU-256 over 128 tokens, LSTM-512 and postnet GRU-256 over 841 frames; the step\'s critical stream)', trunk),
                      ('predictors (3 x GRU, side stream, overlapped; the event pairs include the device-side waits behind the trunk\'s launches)', side)):
         if not acc['launches']:
             continue
