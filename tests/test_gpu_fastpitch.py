@@ -19,7 +19,8 @@ def _bg(kind, A, lda, sA, Bm, ldb, sB, C, ldc, sC, M, N, K, nb0, nb1):
 
 @pytest.mark.parametrize('B,nh,T,hd', [(2, 2, 9, 4), (3, 1, 37, 8), (2, 2, 130, 64), (1, 4, 64, 7)])
 def test_strided_batch_gemms(B, nh, T, hd):
-    """QK^T (NT), PV (NN) and P^T dO (TN) straight out of / into the interleaved [B,T,3d] projection buffer."""
+    """QK^T (NT), PV (NN) and P^T dO (TN) straight out of / into the interleaved [B,T,3d] projection buffer.
+"""
     g = torch.Generator().manual_seed(B * 100 + T)
     d = nh * hd
     qkv = torch.randn(B, T, 3 * d, generator=g)
@@ -47,12 +48,16 @@ def test_strided_batch_gemms(B, nh, T, hd):
     assert torch.isnan(out[..., :d]).all() and torch.isnan(out[..., 2 * d:]).all()      # neighbours untouched
 
 
-@pytest.mark.parametrize('B,nh,T,hd', [(2, 2, 37, 8), (2, 2, 841, 64), (1, 3, 130, 32), (1, 1, 7, 4)])
+@pytest.mark.parametrize('B,nh,T,hd', [(2, 2, 37, 8), (2, 2, 841, 64), (1, 3, 130, 32), (1, 1, 7, 4), (19, 2, 841, 128)])
 def test_row_padded_attention_gemms(B, nh, T, hd):
     """PV (NN) and P^T dO (TN) with the [T,T] operand stored at a row stride rounded up to 4 and flagged as padded
     (the aligned 16-B-load paths; T = 841 is the benchmark's frame count): the pad columns hold NaNs here to prove that
-    whatever lies behind column T-1 is ignored (NN) or only reaches masked outputs (TN)."""
+    whatever lies behind column T-1 is ignored (NN) or only reaches masked outputs (TN).  The last case is the flagship
+    FastPitch's frame-side attention (head width 128) at a batch that sends the TN product to the software-pipelined
+    128x128 kernel in its strided-batch form (the launch counter proves it)."""
+    from forwardtacotron_amd import _lib
     from forwardtacotron_amd.fastpitch import _bgemm
+    n_pipe0 = _lib.query('ft_gemm_tn_pipelined_launches')
     g = torch.Generator().manual_seed(B * 10 + T)
     d = nh * hd
     Tp = (T + 3) // 4 * 4
@@ -75,6 +80,8 @@ def test_row_padded_attention_gemms(B, nh, T, hd):
     want = (P.transpose(-1, -2) @ q).permute(0, 2, 1, 3).reshape(B, T, d)
     assert maxdiff(out[..., d:2 * d].cpu(), want) < tol
     assert torch.isnan(out[..., :d]).all() and torch.isnan(out[..., 2 * d:]).all()
+    if hd == 128:
+        assert _lib.query('ft_gemm_tn_pipelined_launches') - n_pipe0 == 1
 
 
 @pytest.mark.parametrize('B,T,d,nh,masked', [(3, 9, 16, 2, True), (2, 70, 32, 4, True), (2, 33, 24, 3, False)])
