@@ -5,6 +5,10 @@
 #include <string.h>
 
 #include "../../include/fwdtaco_hip.h"
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "ft_gemm.h"
 
 static thread_local char g_err[512] = "";
@@ -32,6 +36,28 @@ int ft_lr_bwd_impl(const float*, const int*, float*, int, int, int, int, hipStre
 // ft_bn.hip: statistics partials by the stand-alone column pass (C++ linkage), and the partial-buffer size query
 int ft_bn_stat_partials(const float* y, int B, int Tbuf, int C, int group, double* partial, hipStream_t s);
 extern "C" size_t ft_conv_stats_workspace(int B, int Tbuf, int C);
+
+// Workgroup slots of the 2-per-CU GEMM kernels on a stream (512 on an unrestricted one): the weight-gradient planner sizes
+// its one-wave grids by it (ft_gemm.hip: plan_tn).
+namespace {
+std::mutex g_slots_mu;
+std::vector<std::pair<hipStream_t, int>> g_stream_slots;
+}  // namespace
+void ft_note_stream_slots(hipStream_t s, int slots) {
+  std::lock_guard<std::mutex> lk(g_slots_mu);
+  for (auto& e : g_stream_slots)
+    if (e.first == s) {
+      e.second = slots;
+      return;
+    }
+  g_stream_slots.push_back({s, slots});
+}
+int ft_stream_slots(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_slots_mu);
+  for (const auto& e : g_stream_slots)
+    if (e.first == s) return e.second;
+  return 512;
+}
 
 extern "C" {
 
@@ -69,9 +95,11 @@ int ft_stream_create_cu_limited(int cus_per_xcd, void** stream) {
     return FT_ERR_HIP;
   }
   *stream = (void*)s;
+  ft_note_stream_slots(s, 2 * 8 * cus_per_xcd);
   return FT_OK;
 }
 int ft_stream_destroy(void* stream) {
+  if (stream) ft_note_stream_slots((hipStream_t)stream, 512);
   if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
     ft_set_error("ft_stream_destroy: hipStreamDestroy failed");
     return FT_ERR_HIP;

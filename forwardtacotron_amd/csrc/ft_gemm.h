@@ -121,6 +121,9 @@ int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per
                          hipStream_t stream);
 // ft_planes.hip: planes pointer for a B operand (first row / k chunk of the launch) or nullptr
 const void* ft_planes_lookup(const float* b, long ldb, long rows_needed);
+// ft_capi_core.hip: workgroup slots (2 per usable CU) of a stream -- 512 unless it is CU-limited
+void ft_note_stream_slots(hipStream_t s, int slots);
+int ft_stream_slots(hipStream_t s);
 bool ft_gemm_b3_enabled();
 // 0 = fp32-exact (default), 1 = bf16 operands / fp32 accumulate on every NT-form fast launch (ft_set_gemm_precision)
 int ft_gemm_precision();

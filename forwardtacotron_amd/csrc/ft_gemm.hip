@@ -527,7 +527,7 @@ int tn_b3_mode() {
 
 // split path usable (aligned operands): its 128x128 tile runs ~1.35x the f32 kernels' rate, so it is preferred whenever
 // tiles x split-K can still fill the chip -- the extra slabs it needs cost a few microseconds of HBM traffic
-TNPlan plan_tn(const FtGemmTNTask& t, bool b3_ok) {
+TNPlan plan_tn(const FtGemmTNTask& t, bool b3_ok, long slots = 512) {
   TNPlan p;
   const int nz = t.nz > 1 ? t.nz : 1;
   long maxs = (t.R + 4 * BK - 1) / (4 * BK);      // at least 128 rows per split
@@ -539,17 +539,17 @@ TNPlan plan_tn(const FtGemmTNTask& t, bool b3_ok) {
   p.tm = p.tn = small ? 1 : 2;
   int bm = 64 * p.tm;
   long tiles = (long)ft_cdiv(t.M, bm) * ft_cdiv(t.N, bm) * t.taps * nz;
-  long want = tiles >= 512 ? 1 : (512 + tiles - 1) / tiles;
+  long want = tiles >= slots ? 1 : (slots + tiles - 1) / tiles;
   // the split-path kernel holds exactly 2 workgroups per CU (53 KB LDS, 220 VGPRs) = 512 slots: a grid slightly above
   // one full wave pays a second, nearly empty one (576 workgroups ran at 94 TF, 512 at 134) -> round DOWN there
   const bool split_path = b3_ok && tn_b3_mode() >= 1 && p.tm == 2;
-  if (split_path && tiles < 512) want = 512 / tiles;
+  if (split_path && tiles < slots) want = slots / tiles;
   if (t.bankC > 0) {
     // conv-bank mode: member kk only has taps j < kk, i.e. (K+1)/(2K) of the grid does work; aim for ~4 waves of
     // workgroups so that the last, partial wave costs little
     const long K = t.taps;
     const long live = tiles * (K + 1) / (2 * K);
-    want = (2048 + live - 1) / (live > 0 ? live : 1);
+    want = (4 * slots + live - 1) / (live > 0 ? live : 1);
   }
   static const long force_s = [] {             // FT_TN_FORCE_S=<n>: tuning aid (lab/tn_split_lab.py)
     const char* e = getenv("FT_TN_FORCE_S");
@@ -731,7 +731,7 @@ int ft_launch_gemm_tn(const FtGemmTNTask& task_in, float* workspace, size_t work
   const bool m_ok = t.M % 4 == 0 || (t.rowpad && t.lda >= ((t.M + 3) & ~3));
   const bool n_ok = t.N % 4 == 0 || (t.rowpad && t.ldb >= ((t.N + 3) & ~3));
   const bool fast = t.a_vec && t.b_vec && m_ok && n_ok;
-  TNPlan p = plan_tn(t, fast);
+  TNPlan p = plan_tn(t, fast, ft_stream_slots(stream));       // a CU-limited stream has fewer slots: fewer, longer splits
   size_t need = (size_t)p.S * t.taps * t.nz * t.M * t.N;
   FT_REQUIRE(workspace && workspace_floats >= need, "gemm_tn: workspace too small (%zu < %zu floats)",
              workspace_floats, need);

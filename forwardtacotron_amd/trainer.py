@@ -29,6 +29,8 @@ from . import hip as H
 from . import ops
 from .parallel import BucketedAllReduce, FlatParams
 
+_CU_LIMITED_STREAMS: Dict[tuple, 'torch.cuda.Stream'] = {}
+
 DEFAULT_TRAIN_CFG = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss_factor=0.1,
                          pitch_zoneout=0.0, energy_zoneout=0.0, clip_grad_norm=1.0)
 
@@ -61,7 +63,9 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reducer = BucketedAllReduce(self.flat, process_group, bucket_bytes)
         # weight gradients are written straight into the flat buffer, the GEMM-shaped ones on a side stream
-        self.wgrad_stream = self._make_wgrad_stream(dev)
+        # models with a recurrent trunk: 28 CUs per XCD by default (see _make_wgrad_stream); FT_WGRAD_CUS overrides
+        self.wgrad_stream = self._make_wgrad_stream(dev, None if 'FT_WGRAD_CUS' in os.environ
+                                                    else (28 if hasattr(model, 'lstm') else 0))
         self.reducer.streams.add(self.wgrad_stream)
         self.sink = ops.GradSink({p.data_ptr(): (i, p.grad) for i, p in enumerate(self.flat.params)},
                                  stream=self.wgrad_stream, on_write=self.reducer.notify)
@@ -73,20 +77,31 @@ class TrainStep:
         self._gc_frozen = os.environ.get('FT_GC_FREEZE', '1') != '1'
 
     @staticmethod
-    def _make_wgrad_stream(dev) -> 'torch.cuda.Stream':
-        """The weight-gradient side stream.  FT_WGRAD_CUS=n (1..31) restricts it to n CUs of every XCD
-        (ft_stream_create_cu_limited): a weight-gradient GEMM is ONE resident wave of long-running workgroups that fills the
-        register file of every CU it may use, so the step's critical stream -- however high its priority -- found no slot
-        for its small dependent kernels until the whole GEMM had drained; a few CUs per XCD kept out of the side stream's
-        reach are always open to it.  0 / 32: an ordinary stream."""
+    def _make_wgrad_stream(dev, n: Optional[int] = None) -> 'torch.cuda.Stream':
+        """The weight-gradient side stream, restricted to n CUs of every XCD (ft_stream_create_cu_limited; 0 / 32: an
+        ordinary stream).  A weight-gradient GEMM is ONE resident wave of long-running workgroups that fills the register
+        file of every CU it may use, so the step's critical stream -- however high its priority -- finds no slot for its
+        small dependent kernels until the whole GEMM has drained: in the tail of a ForwardTacotron step the LSTM's four
+        weight gradients and the prenet's backward chain of ~150 small kernels ran one after the other in effect.  With 4
+        CUs per XCD out of the side stream's reach (and the weight-gradient planner sizing its one-wave grids by the
+        stream's slots, ft_stream_slots) the recurrent models gain 0.3 ms per step (24.15 -> 23.85, same box; 24 / 26 /
+        30 CUs: 23.85-24.0 / 23.95 / 23.93, 20: 24.3); FastPitch, all of whose weight gradients share the stream with
+        nothing recurrent to hide behind, loses (bf16 18.2 -> 19.0) and keeps an ordinary stream."""
         import ctypes
-        n = int(os.environ.get('FT_WGRAD_CUS', '0'))
+        if n is None:
+            n = int(os.environ.get('FT_WGRAD_CUS', '0'))
         if n <= 0 or n >= 32:
             return torch.cuda.Stream(device=dev)
-        with torch.cuda.device(dev):
-            h = ctypes.c_void_p()
-            _lib.call('ft_stream_create_cu_limited', n, ctypes.byref(h))
-        return torch.cuda.ExternalStream(h.value, device=dev)
+        # one such stream per (device, n) and process, shared by every TrainStep and never destroyed: the caching
+        # allocator may still record events on it for tensors that outlive the TrainStep which used it
+        key = (torch.device(dev).index or 0, n)
+        st = _CU_LIMITED_STREAMS.get(key)
+        if st is None:
+            with torch.cuda.device(dev):
+                h = ctypes.c_void_p()
+                _lib.call('ft_stream_create_cu_limited', n, ctypes.byref(h))
+            st = _CU_LIMITED_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=dev)
+        return st
 
     def _weight_packs(self) -> H.PackCache:
         """the re-laid-out weight copies of this model (hip.PackCache), rebuilt only if the flat buffer moved"""
