@@ -1325,8 +1325,13 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   // measured 5.65 us/step against 3.77 for the 8-unit form on the agent-scope protocol (lab/rnn_step_us.py): off by
   // default (FT_RNN_FWD_UB16=1 enables it), kept for the day the register diet succeeds
   const bool wide = b3 && NW == 8 && G == 4 && H / 8 > 32 && H % 16 == 0 && bpw <= 2 && env_int("FT_RNN_FWD_UB16", 0);
+  // GRU, H = 256 (the trunk's two GRUs; the postnet's runs 841 steps): 8 waves with ONE resident k-block each and 16
+  // hidden units per workgroup -- 16 producers per group instead of 32, half the operand bytes per wave.  Same box,
+  // us per step at T = 841 (lab/gru256_ab.py): 4 waves x 2 blocks x 8 units 2.03 | 8 x 1 x 8: 2.03-2.07 | 4 x 2 x 16:
+  // 2.04 | 8 x 1 x 16: 1.78-1.81 | 8 x 1 x 32: 2.30.  FT_RNN_GRU_WIDE=0: the 4-wave 8-unit form.
+  const bool gru_wide = G == 3 && H == 256 && b3 && NW == 4 && env_int("FT_RNN_GRU_WIDE", 1);
   Geom geo;
-  geo.nchunks = H / (wide ? 16 : 8);
+  geo.nchunks = H / ((wide || gru_wide) ? 16 : 8);
   geo.nbg = ft_cdiv(B, MB);
   geo.total = 2 * geo.nbg * geo.nchunks;
   geo.xcd_aware = env_int("FT_RNN_XCDMAP", 1);
@@ -1339,6 +1344,9 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.gran = 0;
   a.s = 0;
   if (wide) return launch_fwd_persist<G, 8, true, 16, 2>(a, geo, p, stream);
+  if constexpr (G == 3) {
+    if (gru_wide) return launch_fwd_persist<G, 8, true, 16, 1>(a, geo, p, stream);
+  }
   if (b3) {
     if (NW == 8) return bpw <= 1 ? launch_fwd_persist<G, 8, true, 8, 1>(a, geo, p, stream)
                                  : launch_fwd_persist<G, 8, true, 8, 2>(a, geo, p, stream);     // (NW = 8: bpw <= 2)
@@ -1424,6 +1432,8 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   }
   PersistWs p = carve_ws(ws, 2 * geo.nbg, K);
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
+  // (GRU H = 256, K = 768 on 16 waves with 2 of the 24 k-blocks each instead of 8 x 3: 11.9 us per step against 2.45 --
+  //  a 1024-thread workgroup caps a lane at 128 registers; lab/gru256_ab.py)
   if (K % 32 == 0 && ft_cdiv(K / 32, NW) <= GW / 2 && env_int("FT_RNN_B3", 1)) {
     if (NW == 16) return launch_bwd_persist<G, 16, 16, true>(a, geo, p, stream);
     if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, true>(a, geo, p, stream)
