@@ -323,11 +323,14 @@ class ForwardTacotron(nn.Module):
             self._nbt_flat = f
         f += 1
 
-    def _trunk(self, x: torch.Tensor, dur: torch.Tensor, pitch: torch.Tensor, energy: torch.Tensor,
-               mel_lens: Optional[torch.Tensor]):
+    def _trunk(self, x: torch.Tensor, dur, pitch, energy, mel_lens: Optional[torch.Tensor], late_inputs=None):
+        """late_inputs (inference): a callable that delivers (dur, pitch, energy) once the prenet has been enqueued -- the
+        predictors then run on a side stream beside embedding + prenet CBHG instead of in front of them"""
         B = x.shape[0]
         x = ops.EmbeddingFn.apply(x, self.embedding.weight)
         x = self.prenet(x, time_major_out=True)                             # [Tx,B,2P] (recurrence layout)
+        if late_inputs is not None:
+            dur, pitch, energy = late_inputs()
         x = ops.CondAddFn.apply(x, pitch, energy, self.pitch_proj.weight, self.pitch_proj.bias,
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
                                 self.energy_strength, True)                 # -> [B,Tx,2P]
@@ -417,12 +420,34 @@ class ForwardTacotron(nn.Module):
 
     def _generate(self, x, alpha, pitch_function, energy_function):
         self._require_device(x)
-        dur_hat = self.dur_pred(x, alpha=alpha).squeeze(2)
-        if torch.sum(dur_hat.long()) <= 0:
-            torch.fill_(dur_hat, value=2.)
-        pitch_hat = pitch_function(self.pitch_pred(x).transpose(1, 2))
-        energy_hat = energy_function(self.energy_pred(x).transpose(1, 2))
-        return self._generate_mel(x, dur_hat, pitch_hat, energy_hat)
+        # The predictors only meet the trunk behind the prenet (forward_tacotron.py:168-189 runs them first, then the
+        # prenet): they run on the side stream while the main stream does embedding + prenet CBHG (its 128-step GRU is
+        # latency-bound: a single utterance spends 84 % of its time in recurrences), joined where their outputs are needed.
+        import os
+        main = torch.cuda.current_stream()
+        side = self._side_stream(x.device) if os.environ.get('FT_GEN_OVERLAP', '1') == '1' else main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dur_hat = self.dur_pred(x, alpha=alpha).squeeze(2)
+            pitch_hat = pitch_function(self.pitch_pred(x).transpose(1, 2))
+            energy_hat = energy_function(self.energy_pred(x).transpose(1, 2))
+        got = {}
+
+        def late_inputs():
+            main.wait_stream(side)
+            H.rnn_note_join(main, side)
+            for t in (dur_hat, pitch_hat, energy_hat):
+                t.record_stream(main)
+            if torch.sum(dur_hat.long()) <= 0:
+                torch.fill_(dur_hat, value=2.)
+            got['dur'] = dur_hat.contiguous()
+            return (got['dur'], pitch_hat.reshape(x.shape[0], -1).contiguous(),
+                    energy_hat.reshape(x.shape[0], -1).contiguous())
+
+        mel_cl, post_cl = self._trunk(x, None, None, None, None, late_inputs=late_inputs)
+        T = mel_cl.shape[1]
+        return {'mel': H.transpose_pad_fwd(mel_cl, T, 0.0), 'mel_post': H.transpose_pad_fwd(post_cl, T, 0.0),
+                'dur': got['dur'], 'pitch': pitch_hat, 'energy': energy_hat}
 
     def _generate_mel(self, x: torch.Tensor, dur_hat: torch.Tensor, pitch_hat: torch.Tensor,
                       energy_hat: torch.Tensor) -> Dict[str, torch.Tensor]:

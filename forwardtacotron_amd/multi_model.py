@@ -150,10 +150,14 @@ class MultiForwardTacotron(nn.Module):
             self._nbt_flat = f
         f += 1
 
-    def _trunk(self, x, semb, dur, pitch, energy, mel_lens: Optional[torch.Tensor]):
+    def _trunk(self, x, semb, dur, pitch, energy, mel_lens: Optional[torch.Tensor], late_inputs=None):
+        """late_inputs (inference): delivers (dur, pitch, energy) once the prenet has been enqueued (see
+        model.ForwardTacotron._trunk: the predictors run beside the prenet on the side stream)"""
         B, Tx = x.shape
         x = ops.EmbeddingFn.apply(x, self.embedding.weight)
         x = self.prenet(x, time_major_out=True)                                  # [Tx,B,2P]
+        if late_inputs is not None:
+            dur, pitch, energy = late_inputs()
         x = ops.ConcatColsFn.apply(x, None, semb, B, Tx, True)                   # [B,Tx,2P+S]
         x = ops.CondAddFn.apply(x, pitch, energy, self.pitch_proj.weight, self.pitch_proj.bias,
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
@@ -223,20 +227,34 @@ class MultiForwardTacotron(nn.Module):
         with torch.no_grad():
             self._require_device(x)
             speaker_emb = speaker_emb.contiguous()
-            pitch_cond_hat = self.pitch_cond_pred(x, speaker_emb).squeeze(-1)
-            pitch_cond_hat = torch.argmax(pitch_cond_hat.squeeze(), dim=1).long().unsqueeze(0)
-            dur_hat = self.dur_pred(x, pitch_cond_hat, speaker_emb, alpha=alpha).squeeze(-1)
-            if torch.sum(dur_hat.long()) <= 0:
-                torch.fill_(dur_hat, value=2.)
-            pitch_hat = pitch_function(self.pitch_pred(x, pitch_cond_hat, speaker_emb).transpose(1, 2))
-            energy_hat = energy_function(self.energy_pred(x, speaker_emb).transpose(1, 2))
-            dur_in = dur_hat.contiguous()
+            # the four predictors beside embedding + prenet CBHG (side stream), joined where the trunk needs them
+            import os
+            main = torch.cuda.current_stream()
+            side = self._side_stream(x.device) if os.environ.get('FT_GEN_OVERLAP', '1') == '1' else main
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pitch_cond_hat = self.pitch_cond_pred(x, speaker_emb).squeeze(-1)
+                pitch_cond_hat = torch.argmax(pitch_cond_hat.squeeze(), dim=1).long().unsqueeze(0)
+                dur_hat = self.dur_pred(x, pitch_cond_hat, speaker_emb, alpha=alpha).squeeze(-1)
+                pitch_hat = pitch_function(self.pitch_pred(x, pitch_cond_hat, speaker_emb).transpose(1, 2))
+                energy_hat = energy_function(self.energy_pred(x, speaker_emb).transpose(1, 2))
             B = x.shape[0]
-            mel_cl, post_cl = self._trunk(x, speaker_emb, dur_in, pitch_hat.reshape(B, -1).contiguous(),
-                                          energy_hat.reshape(B, -1).contiguous(), None)
+            got = {}
+
+            def late_inputs():
+                main.wait_stream(side)
+                H.rnn_note_join(main, side)
+                for t in (pitch_cond_hat, dur_hat, pitch_hat, energy_hat):
+                    t.record_stream(main)
+                if torch.sum(dur_hat.long()) <= 0:
+                    torch.fill_(dur_hat, value=2.)
+                got['dur'] = dur_hat.contiguous()
+                return got['dur'], pitch_hat.reshape(B, -1).contiguous(), energy_hat.reshape(B, -1).contiguous()
+
+            mel_cl, post_cl = self._trunk(x, speaker_emb, None, None, None, None, late_inputs=late_inputs)
             T = mel_cl.shape[1]
             return {'mel': H.transpose_pad_fwd(mel_cl, T, 0.0), 'mel_post': H.transpose_pad_fwd(post_cl, T, 0.0),
-                    'dur': dur_in, 'pitch': pitch_hat, 'energy': energy_hat,
+                    'dur': got['dur'], 'pitch': pitch_hat, 'energy': energy_hat,
                     'pitch_cond': pitch_cond_hat.unsqueeze(1)}
 
     def _side_stream(self, device) -> 'torch.cuda.Stream':
