@@ -1433,7 +1433,7 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   PersistWs p = carve_ws(ws, 2 * geo.nbg, K);
   if (ws_bytes < p.total_bytes || p.xb_bytes >= (1ull << 31)) return -1;
   // (GRU H = 256, K = 768 on 16 waves with 2 of the 24 k-blocks each instead of 8 x 3: 11.9 us per step against 2.45 --
-  //  a 1024-thread workgroup caps a lane at 128 registers; lab/gru256_ab.py)
+  //  a 1024-thread workgroup caps a lane at 128 registers; 12 waves x 2 blocks: 5.1 us; lab/gru256_ab.py)
   if (K % 32 == 0 && ft_cdiv(K / 32, NW) <= GW / 2 && env_int("FT_RNN_B3", 1)) {
     if (NW == 16) return launch_bwd_persist<G, 16, 16, true>(a, geo, p, stream);
     if (NW == 8) return GW == 16 ? launch_bwd_persist<G, 8, 16, true>(a, geo, p, stream)
