@@ -103,6 +103,26 @@ class TrainStep:
             st = _CU_LIMITED_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=dev)
         return st
 
+    @staticmethod
+    def _predictors_first(model, B: int) -> bool:
+        """Three-stage backward: may the predictors' stage go first?  Yes iff the largest predictor BPTT grid and the
+        trunk's first BPTT (the postnet CBHG's GRU) are admitted side by side (ft_rnn_persist.hip, admission: per-XCD demand
+        of a backward GRU = H/16 chunks x ceil(groups / 8) over 32 one-workgroup CUs, budget 0.75).  FT_PRED_STAGE_FIRST=0/1
+        overrides.  ForwardTacotron bs=32: 0.5 + 0.25 -> first (24.0 -> 23.6, 23.4 -> 23.1 ms on two boxes);
+        MultiForwardTacotron (a 256-wide pitch predictor): 0.5 + 0.5 -> not first (measured: 27.4 -> 27.8, bs=64 38.0 -> 38.9)."""
+        env = os.environ.get('FT_PRED_STAGE_FIRST')
+        if env is not None:
+            return env == '1'
+        post = getattr(getattr(model, 'postnet', None), 'rnn', None)
+        preds = [m.rnn for n, m in model.named_children() if n.endswith('_pred') and hasattr(m, 'rnn')]
+        if post is None or not preds or not hasattr(post, 'hidden_size'):
+            return False
+        groups = 2 * ((B + 15) // 16)
+
+        def demand(h):
+            return (h // 16) * ((groups + 7) // 8) / 32.0
+        return demand(post.hidden_size) + max(demand(r.hidden_size) for r in preds) <= 0.75
+
     def _weight_packs(self) -> H.PackCache:
         """the re-laid-out weight copies of this model (hip.PackCache), rebuilt only if the flat buffer moved"""
         if self.packs is None or self._packs_base != self.flat.flat.data_ptr():
@@ -259,7 +279,23 @@ class TrainStep:
                 side_root, main_root = L.pop('_roots')
                 cut = getattr(model, '_cut', None)
                 model._cut = None
-                if staged and cut is not None:
+                if staged and cut is not None and self._predictors_first(model, int(batch['x'].shape[0])):
+                    # The predictors' stage issued FIRST: it then runs beside the postnet GRU's BPTT and the postnet's conv
+                    # backward -- the first 4 ms of the backward, of which 2 ms are a recurrence that leaves most of the chip
+                    # idle -- instead of in the tail of the step, where it was the last stream to finish (the LSTM's BPTT,
+                    # which fills its XCD slots, waits on the device for the predictors' BPTT kernels: they are long done).
+                    # Only where the predictors' BPTT grids fit BESIDE the postnet GRU's (_predictors_first): otherwise they
+                    # queue behind it and the stage delays the trunk (multispeaker: 38.0 -> 38.9 ms).
+                    here = torch.cuda.current_stream()
+                    pstream = model._side_stream(side_root.device)
+                    pstream.wait_stream(here)
+                    with torch.cuda.stream(pstream):
+                        side_root.backward()
+                    side_root.record_stream(pstream)
+                    self.sink.used.add(pstream)
+                    main_root.backward()
+                    cut[0].backward(cut[1].grad)
+                elif staged and cut is not None:
                     main_root.backward()
                     # backward() ends by making the CALLING stream wait for every stream it ran nodes on: called from
                     # the main stream the predictors' stage would simply be inserted into the critical path.  It is

@@ -260,10 +260,11 @@ def test_recurrence_fault_fallback_policy_continues_on_per_step_kernels():
         _lib.lib().ft_rnn_set_persistent(1)
 
 
-@pytest.mark.parametrize('env', [{'FT_PRED_BWD_EARLY': '1'}, {'FT_STAGED_BACKWARD': '0'}, {'FT_WGRAD_CUS': '0'}])
+@pytest.mark.parametrize('env', [{'FT_PRED_BWD_EARLY': '1'}, {'FT_STAGED_BACKWARD': '0'}, {'FT_PRED_STAGE_FIRST': '0'},
+                                 {'FT_WGRAD_CUS': '0'}])
 def test_step_schedule_variants_give_the_same_update(env, monkeypatch):
-    """The backward of a step can be scheduled in several ways -- three stages with the predictors in the middle (the
-    default), one backward call, the predictors' backward issued from inside the forward (model.predictor_hook), the
+    """The backward of a step can be scheduled in several ways -- three stages with the predictors' stage first (the
+    default where their BPTT grids fit beside the postnet GRU's) or in the middle, one backward call, the predictors' backward issued from inside the forward (model.predictor_hook), the
     weight-gradient stream unrestricted instead of limited to 28 CUs per XCD (ft_stream_create_cu_limited: fewer slots,
     so the weight-gradient planner picks other split counts -- the slabs are still summed in a fixed order, but a
     different one: this variant is compared to rounding, the others bit for bit) -- and every parameter's gradient
