@@ -57,9 +57,16 @@ class GradSink:
         # whose weight gradient is still reading it on the side stream has returned (seen as rare wrong conv2 weight
         # gradients in MultiFastPitch's predictors).  A live reference makes autograd add out of place instead.
         self.keep = []
+        # late_ok (set per step by the trainer): weight gradients emitted with late=True are not sent to the side stream but
+        # run on the step's MAIN stream at the very end of the backward (flush_deferred) -- with the predictors' stage out of
+        # the tail the main stream finishes its chain 0.8 ms before the side stream has worked off the LSTM's four weight
+        # gradients; one of the four rebalances the two.
+        self.late_ok = False
+        self.late = []
 
     def begin_step(self):
         self.written.clear()
+        self.late.clear()
         self.pending.clear()
         self.held.clear()
         self.used.clear()
@@ -162,11 +169,22 @@ def flush_end(pend) -> None:
 
 
 def flush_deferred() -> None:
-    """issue every queued side-stream weight gradient (no-op without a deferring sink)"""
+    """issue every queued side-stream weight gradient (no-op without a deferring sink), then the ones kept for the end of
+    the main stream's chain (GradSink.late)"""
     flush_end(flush_begin())
+    sink = _SINK
+    if sink is not None and sink.late:
+        late, sink.late = sink.late, []
+        for compute, view, deps, idx in late:
+            compute(view)
+            sink.keep.append(deps)
+            sink.held.discard(idx)
+            sink.used.add(torch.cuda.current_stream())
+            if sink.on_write is not None:
+                sink.on_write(idx)
 
 
-def _emit(w: torch.Tensor, compute, deps=(), heavy=True):
+def _emit(w: torch.Tensor, compute, deps=(), heavy=True, late: bool = False):
     """Produces the gradient of parameter `w`: compute(out) must overwrite `out` (same shape as w).
     Without a sink: returns a fresh tensor (autograd accumulates it).  With a sink: writes the flat-buffer
     view (on the side stream when `heavy`) and returns None.  heavy='light': a small reduction (bias gradient) that nothing
@@ -178,6 +196,11 @@ def _emit(w: torch.Tensor, compute, deps=(), heavy=True):
         compute(out)
         return out
     idx, view = ent
+    if late and _SINK.late_ok and _SINK.defer:
+        _SINK.written.add(idx)
+        _SINK.held.add(idx)             # claimed; the all-reduce hears about it when it is issued
+        _SINK.late.append((compute, view, deps, idx))
+        return None
     if heavy == 'light':
         heavy = _SINK.defer and bool(deps) and os.environ.get('FT_BIAS_GRADS_SIDE', '1') == '1'
     side = _SINK.stream if heavy else None
@@ -457,7 +480,7 @@ class HighwayFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
-def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx):
+def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx, late_last=False):
     """Shared tail of the GRU/LSTM backward: weight / bias / input gradients from the per-step
     pre-activation gradients (dxp wrt input projection, dhp wrt hidden projection).
     x is batch-major [B,T,I]; dxp / dhp / hid are the recurrence's time-major [T,B,*] buffers.
@@ -482,7 +505,7 @@ def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx):
             px, 2 * GH, x.data_ptr(), I, out, rows, I, GH, B=B, T=T, dy_tm=True, x_tm=False), (dxp, x))
         g_hh = _emit(w_hh, lambda out, ph=ph, d=d: H.linear_bwd_weight_raw(
             ph, 2 * GH, hid.data_ptr() + d * Hh * _F4, 2 * Hh, out, rows, Hh, GH, B=B, T=T,
-            x_shift=-1 if d == 0 else 1, dy_tm=True, x_tm=True), (dhp, hid))
+            x_shift=-1 if d == 0 else 1, dy_tm=True, x_tm=True), (dhp, hid), late=late_last and d == 1)
         grads += [g_ih, g_hh, gb[2 * d], gb[2 * d + 1]]
     return dx, grads
 
@@ -544,7 +567,8 @@ class BiLSTMFn(Function):
         dg = H.lstm_bwd(dout_tm, raw, cst, gates, H.transpose2d(params[1]),
                         H.transpose2d(params[5]), lens if ctx.has_lens else None, Hh)
         flush_end(pend)
-        dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, params, ctx.needs_input_grad[0])
+        # (one of the decoder LSTM's four weight gradients may run at the end of the main stream's chain: GradSink.late)
+        dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, params, ctx.needs_input_grad[0], late_last=True)
         return (dx, None, None, *g)
 
 

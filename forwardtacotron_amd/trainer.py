@@ -279,7 +279,9 @@ class TrainStep:
                 side_root, main_root = L.pop('_roots')
                 cut = getattr(model, '_cut', None)
                 model._cut = None
-                if staged and cut is not None and self._predictors_first(model, int(batch['x'].shape[0])):
+                first = staged and cut is not None and self._predictors_first(model, int(batch['x'].shape[0]))
+                self.sink.late_ok = first and os.environ.get('FT_WGRAD_LATE', '1') == '1'
+                if first:
                     # The predictors' stage issued FIRST: it then runs beside the postnet GRU's BPTT and the postnet's conv
                     # backward -- the first 4 ms of the backward, of which 2 ms are a recurrence that leaves most of the chip
                     # idle -- instead of in the tail of the step, where it was the last stream to finish (the LSTM's BPTT,

@@ -261,7 +261,7 @@ def test_recurrence_fault_fallback_policy_continues_on_per_step_kernels():
 
 
 @pytest.mark.parametrize('env', [{'FT_PRED_BWD_EARLY': '1'}, {'FT_STAGED_BACKWARD': '0'}, {'FT_PRED_STAGE_FIRST': '0'},
-                                 {'FT_WGRAD_CUS': '0'}])
+                                 {'FT_WGRAD_LATE': '0'}, {'FT_WGRAD_CUS': '0'}])
 def test_step_schedule_variants_give_the_same_update(env, monkeypatch):
     """The backward of a step can be scheduled in several ways -- three stages with the predictors' stage first (the
     default where their BPTT grids fit beside the postnet GRU's) or in the middle, one backward call, the predictors' backward issued from inside the forward (model.predictor_hook), the
