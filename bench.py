@@ -13,7 +13,7 @@ Rank 0 prints ONE JSON line (driver contract) with two extra objects:
   roofline     : the dominant GEMM launch (postnet conv bank forward) timed LIVE with a HIP event pair on its launch
                  stream inside every timed step -- algorithmic fp32 TFLOP/s against the f32 MFMA peak, the executed bf16
                  rate against the dense bf16 peak, HBM traffic per launch read from the committed PMC summary named in
-                 `traffic_source` -- plus `families`: the TIME-dominant kernel family (the persistent recurrences,
+                 `traffic_source` -- plus `families`: the weight-gradient GEMM in isolation, the TIME-dominant kernel family (the persistent recurrences,
                  latency-bound) and the LengthRegulator (HBM-bound), timed with event pairs in a short instrumented pass
                  AFTER the timed region (32 extra event records per step would perturb it), and whole-step TFLOP/s
   cpu_baseline : the reference step restated on stock fused torch CPU ops (oracle/ft_torch_cpu.py, pinned to the
@@ -203,6 +203,45 @@ def lr_back_to_back_ms(hip_mod, args, n=50):
     return e0.elapsed_time(e1) / n
 
 
+def wgrad_family(hip_mod, device, n=20):
+    """The weight-gradient GEMM of the step with the most FLOPs per launch -- the decoder LSTM's W_ih gradient of one
+    direction: dW[2048,512] = dgates[26912 rows, time-major, 2048 of 4096 columns]^T x[26912,512] -- launched n times back
+    to back between one event pair (in the step these launches run on the side stream beside other work; their in-step
+    durations are contended).  One launch = ft_gemm_tn_b3p_kernel (4 row splits) + the ordered slab sum."""
+    B, T, I, GH = 32, 841, 512, 2048
+    g = torch.Generator(device='cpu').manual_seed(3)
+    dy = torch.randn(T, B, 2 * GH, generator=g).to(device)
+    x = torch.randn(B, T, I, generator=g).to(device)
+    dw = torch.empty(GH, I, device=device)
+
+    def launch():
+        hip_mod.linear_bwd_weight_raw(dy.data_ptr(), 2 * GH, x.data_ptr(), I, dw, B * T, I, GH, B=B, T=T, dy_tm=True,
+                                      x_tm=False)
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * B * T * I * GH
+    ach = flops / (ms * 1e-3) / 1e12
+    b3 = os.environ.get('FT_GEMM_B3', '1') != '0'
+    piped = os.environ.get('FT_GEMM_TN_PIPE', '1') != '0'
+    rec = {'family': 'weight-gradient GEMM (decoder LSTM W_ih, one direction: 2048 x 512 over 26912 time-major rows)',
+           'bound': 'mfma', 'kernels': ('ft_gemm_tn_b3p_kernel' if piped else 'ft_gemm_tn_b3_kernel') if b3 else 'ft_gemm_tn_kernel',
+           'launch_ms': round(ms, 4), 'timing': f'{n} launches back to back between one event pair (incl. the ordered slab sum)',
+           'flops_per_launch': flops, 'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'frac': round(ach / F32_MFMA_PEAK_TFLOPS, 4)}
+    if b3:
+        rec['pipe'] = 'bf16 MFMA x6 per fp32 product (exact 3-way split, fp32 accumulate)'
+        rec['executed_bf16_tflops'] = round(6 * ach, 1)
+        rec['frac_of_bf16_dense_peak'] = round(6 * ach / BF16_MFMA_PEAK_TFLOPS, 4)
+    return rec
+
+
 def cpu_baseline(model_cfg, train_cfg, budget_s, threads):
     """The reference step on stock fused torch CPU ops (oracle/ft_torch_cpu.py), SAME bs=32 seed-0 batch as the GPU
     run: a B=2 warm-up step (thread pools, allocator), then whole bs=32 steps while they fit the budget (at least
@@ -350,6 +389,7 @@ def main():
             fp.remove()
             lr_iso = lr_back_to_back_ms(_hip, fp.lr_args) if getattr(fp, 'lr_args', None) else None
             fam = family_rooflines(fp.results(), args.family_steps, batch, elapsed / args.steps * 1e3, lr_iso)
+            fam.append(wgrad_family(_hip, device))
         flag = torch.tensor([ok], device=device)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
