@@ -1193,18 +1193,22 @@ int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStr
   if (big && pipelined && span_ok) {
     // weights whose bf16 pieces were prepared this step (ft_planes.hip): if EVERY task's B operand has them, the launch
     // stages B without splitting (BP = true).  Same bits either way.
-    FtGemmBatch pb = batch;
+    const void* pl[FT_MAX_TASKS];
     bool planes = true;
-    const int nt = batch.t[0].nz > 1 ? 1 : ntask;
-    for (int i = 0; i < nt && i < FT_MAX_TASKS && planes; ++i) {
-      FtGemmTask& t = pb.t[i];
+    const int nt = batch.t[0].nz > 1 ? 1 : (ntask < FT_MAX_TASKS ? ntask : FT_MAX_TASKS);
+    for (int i = 0; i < nt && planes; ++i) {
+      const FtGemmTask& t = batch.t[i];
       const long rows_per_tap = t.ldb > 0 ? t.b_tap_stride / t.ldb : 0;
       planes = t.nz <= 1 && t.ldb > 0 && (t.taps <= 1 || (t.b_tap_stride > 0 && t.b_tap_stride % t.ldb == 0)) &&
                128L * ((t.ldb + 15) / 16) * 96 < (1L << 31);
       if (!planes) break;
-      const void* p = ft_planes_lookup(t.B, t.ldb, (long)(t.taps - 1) * rows_per_tap + t.N);
-      planes = p != nullptr;
-      t.B = static_cast<const float*>(p);
+      pl[i] = ft_planes_lookup(t.B, t.ldb, (long)(t.taps - 1) * rows_per_tap + t.N);      // null at once while the mechanism is off
+      planes = pl[i] != nullptr;
+    }
+    FtGemmBatch pb;
+    if (planes) {                                      // (the 4 KB descriptor is only copied for a launch that uses planes)
+      pb = batch;
+      for (int i = 0; i < nt; ++i) pb.t[i].B = static_cast<const float*>(pl[i]);
     }
     if (planes) {
       if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1, true>), grid, dim3(256), 0, stream, pb);

@@ -140,7 +140,18 @@ size_t ft_planes_bytes(long rows, long ld) {
   return (size_t)rows * (size_t)((ld + 15) / 16) * 96;
 }
 
+// (one registry per process: one process drives one GPU -- the registry remembers the device it was first used on and
+//  refuses another)
+static int g_planes_dev = -1;
+static bool planes_device_ok() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (g_planes_dev < 0) g_planes_dev = dev;
+  return g_planes_dev == dev;
+}
+
 int ft_planes_register(const float* w, long rows, long ld, void* planes) {
+  FT_REQUIRE(planes_device_ok(), "ft_planes_register: the planes registry belongs to device %d (one process per GPU)", g_planes_dev);
   FT_REQUIRE(w && planes && rows > 0 && ld > 0 && ld % 4 == 0, "ft_planes_register: rows %ld, ld %ld (ld %% 4 must be 0)", rows, ld);
   FT_REQUIRE(((uintptr_t)w & 15) == 0 && ((uintptr_t)planes & 15) == 0, "ft_planes_register: 16-byte alignment");
   std::lock_guard<std::mutex> lk(g_mu);
