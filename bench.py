@@ -347,7 +347,7 @@ def main():
     def build():
         torch.manual_seed(0)                  # identical initial weights on every rank
         model = ForwardTacotron(**model_cfg).to(device)
-        return TrainStep(model, lr=5e-5, train_cfg=train_cfg)
+        return TrainStep(model, lr=5e-5, train_cfg=train_cfg, gc_freeze=True)   # (process-wide; the application's call)
 
     def measure(ts):
         """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize."""

@@ -30,9 +30,13 @@ __global__ __launch_bounds__(256) void ft_sumsq_partial_kernel(const float* __re
 // fault: the device's sticky recurrence-fault word (ft_rnn_persist.hip).  If a persistent recurrence timed out since the
 // word was last cleared, the gradients of this step are garbage: out[2] = 1 makes ft_adam_kernel skip the update, the
 // coefficient is 0 and the reported norm NaN, so that nothing downstream can mistake the step for a valid one.
+// remote: the data-parallel fault lane (ft_fault_lane_set on every rank, SUM all-reduced with the gradients): > 0 means
+// SOME rank's recurrence faulted, and then every rank's all-reduced gradient is garbage -- every rank skips alike
+// (out[2] = 2 where only another rank faulted).
 __global__ __launch_bounds__(256) void ft_clip_coef_kernel(const double* __restrict__ partial, int nblocks,
                                                            float max_norm, float pre_scale,
                                                            const unsigned* __restrict__ fault,
+                                                           const float* __restrict__ remote,
                                                            float* __restrict__ out) {
   __shared__ double red[4];
   double s = 0.0;
@@ -48,11 +52,27 @@ __global__ __launch_bounds__(256) void ft_clip_coef_kernel(const double* __restr
     c = max_norm / (norm + 1e-6f);
     if (c > 1.0f) c = 1.0f;
   }
-  const bool bad = fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  const bool mine = fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  const bool bad = mine || (remote && !(remote[0] == 0.f));      // (a NaN lane counts as a fault)
   out[0] = bad ? 0.f : c * pre_scale;
   out[1] = bad ? __uint_as_float(0x7fc00000u) : norm;
-  out[2] = bad ? 1.f : 0.f;
+  out[2] = mine ? 1.f : (bad ? 2.f : 0.f);
   out[3] = 0.f;
+}
+
+__global__ void ft_fault_lane_kernel(const unsigned* __restrict__ fault, float* __restrict__ lane) {
+  if (threadIdx.x < 4)
+    lane[threadIdx.x] = (threadIdx.x == 0 && fault &&
+                         __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.f : 0.f;
+}
+
+// dst <- snapshot (4-byte words) iff the step was marked faulted: the buffers a forward pass updates in place (BatchNorm
+// running statistics, num_batches_tracked, `step`) go back to their values from before the faulted step
+__global__ __launch_bounds__(256) void ft_guarded_restore_kernel(unsigned* __restrict__ dst,
+                                                                 const unsigned* __restrict__ snap, long n,
+                                                                 const float* __restrict__ coef) {
+  if (coef[2] == 0.f) return;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = snap[i];
 }
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
@@ -99,8 +119,8 @@ extern "C" {
 
 size_t ft_grad_norm_workspace(void) { return 2048 * sizeof(double); }
 
-int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scale, float* coef_and_norm,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scale, const float* fault_lane,
+                      float* coef_and_norm, void* workspace, size_t workspace_bytes, void* stream) {
   FT_REQUIRE(n >= 0, "clip_grad_norm: bad n");
   FT_REQUIRE(((uintptr_t)grads % 16) == 0, "clip_grad_norm: gradient buffer must be 16-byte aligned");
   FT_REQUIRE(workspace && workspace_bytes >= ft_grad_norm_workspace(), "clip_grad_norm: workspace too small");
@@ -110,8 +130,24 @@ int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scal
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ft_sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, grads, n, (double*)workspace);
   hipLaunchKernelGGL(ft_clip_coef_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, nb, max_norm, pre_scale,
-                     ft_rnn_fault_word(), coef_and_norm);
+                     ft_rnn_fault_word(), fault_lane, coef_and_norm);
   return ft_check_launch("clip_grad_norm");
+}
+
+int ft_fault_lane_set(float* lane, void* stream) {
+  FT_REQUIRE(lane && ((uintptr_t)lane % 16) == 0, "fault_lane_set: lane must be 4 floats, 16-byte aligned");
+  hipLaunchKernelGGL(ft_fault_lane_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ft_rnn_fault_word(), lane);
+  return ft_check_launch("fault_lane_set");
+}
+
+int ft_guarded_restore(void* dst, const void* snapshot, long nwords, const float* coef, void* stream) {
+  FT_REQUIRE(nwords >= 0 && coef, "guarded_restore: bad arguments");
+  if (nwords == 0) return FT_OK;
+  long nb = ft_cdiv(nwords, 256);
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(ft_guarded_restore_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (unsigned*)dst,
+                     (const unsigned*)snapshot, nwords, coef);
+  return ft_check_launch("guarded_restore");
 }
 
 int ft_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,

@@ -76,6 +76,64 @@ class FlatParams:
         self.grad.zero_()
 
 
+class FlatBuffers:
+    """Re-homes the buffers a TRAINING forward pass updates in place -- every BatchNorm's running_mean / running_var
+    (fp32) and num_batches_tracked plus the model's `step` (int64; forward_tacotron.py:101,126-127) -- into one flat
+    tensor per dtype, so that a step can snapshot them with two copies and a faulted step (ft_clip_grad_norm's record)
+    can put them back on the device with two guarded launches: a recurrence fault then leaves NO trace in the model, not
+    only none in the parameters.  Order: all running_means in module order, then all running_vars -- the members of a
+    conv bank stay adjacent, which CBHG._bank_flat relies on -- then the counters in module order, `step` last (the
+    layout model._bump_batchnorm_counters keeps itself).  load_state_dict copies in place and keeps the views;
+    .to() / .cuda() break them: attach() again (TrainStep does)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
+               and m.running_mean is not None]
+        self.bns = bns
+        dev = next(module.parameters()).device
+        fl = [b.running_mean for b in bns] + [b.running_var for b in bns]
+        self.f_sizes = [t.numel() for t in fl]
+        self.stats = (torch.cat([t.detach().reshape(-1).float() for t in fl]) if fl
+                      else torch.zeros(0)).to(dev).contiguous()
+        cnt = [b.num_batches_tracked.detach().reshape(1) for b in bns]
+        self.has_step = isinstance(getattr(module, 'step', None), torch.Tensor) and module.step.dtype == torch.int64
+        if self.has_step:
+            cnt.append(module.step.detach().reshape(1))
+        self.counts = (torch.cat(cnt) if cnt else torch.zeros(0, dtype=torch.int64)).to(dev).contiguous()
+        self.stats_snap = torch.empty_like(self.stats)
+        self.counts_snap = torch.empty_like(self.counts)
+        self.attach()
+
+    def attach(self) -> None:
+        n, off = len(self.bns), 0
+        for j, name in enumerate(('running_mean', 'running_var')):
+            for i, b in enumerate(self.bns):
+                k = self.f_sizes[j * n + i]
+                b._buffers[name] = self.stats[off:off + k].view(getattr(b, name).shape)
+                off += k
+        for i, b in enumerate(self.bns):
+            b._buffers['num_batches_tracked'] = self.counts[i]
+        if self.has_step:
+            self.module._buffers['step'] = self.counts[n:n + 1]
+        if hasattr(self.module, '_nbt_flat') and n:
+            self.module._nbt_flat = self.counts[:n]
+
+    def attached(self) -> bool:
+        if self.has_step and self.module.step.data_ptr() != self.counts.data_ptr() + 8 * len(self.bns):
+            return False
+        return not self.bns or (self.bns[0].running_mean.data_ptr() == self.stats.data_ptr()
+                                and self.bns[-1].num_batches_tracked.data_ptr()
+                                == self.counts.data_ptr() + 8 * (len(self.bns) - 1))
+
+    def snapshot(self) -> None:
+        """values before this step's forward (two device copies on the current stream)"""
+        if self.stats.numel():
+            self.stats_snap.copy_(self.stats)
+        if self.counts.numel():
+            self.counts_snap.copy_(self.counts)
+
+
 class BucketedAllReduce:
     """Sum all-reduce of a flat gradient buffer in buckets, overlapped with backward.
 
@@ -84,9 +142,15 @@ class BucketedAllReduce:
     counters for one backward; `finish()` waits (stream-level) for all launched collectives and launches
     any bucket whose hooks never fired (unused parameters keep their zero gradient)."""
 
-    def __init__(self, flat: FlatParams, process_group=None, bucket_bytes: int = 24 << 20):
+    def __init__(self, flat: FlatParams, process_group=None, bucket_bytes: int = 24 << 20, lane_fill=None):
+        """lane_fill(lane): writes this rank's fault state (1.0 / 0.0) into lane[0] on the current stream.  With it, finish()
+        sum-all-reduces a 4-float FAULT LANE behind the last bucket: a rank whose recurrence faulted has already summed
+        its garbage gradient into every rank's buckets, so every rank must skip the update alike (the optimizer reads the
+        lane, ft_clip_grad_norm).  One 16-byte collective per step, on the communication stream, after the buckets."""
         self.flat = flat
         self.pg = process_group
+        self.lane_fill = lane_fill
+        self.lane = None
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # FT_DP_FORCE_COLLECTIVE=1: a one-rank group still runs every bucket through the backend (a sum over one rank is
         # the identity) -- lets a one-GPU box execute the RCCL launch / communication-stream path for real
@@ -121,9 +185,20 @@ class BucketedAllReduce:
         self.seen = set()
         self.held = None                # set of parameter indices a gradient sink still owes (ops.GradSink.held)
         self.comm_stream = None
+        self._hooks = []
+        if not self.active:
+            self.lane_fill = None           # (single rank, nothing forced through a backend: no lane)
         if self.active:
             for j, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(j))
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(j)))
+
+    def close(self) -> None:
+        """removes the autograd hooks (they hold this object, which holds the parameters: a reference cycle)"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.active = False
+        self.lane_fill = None
 
     def _make_hook(self, j: int):
         def hook(p):
@@ -189,6 +264,22 @@ class BucketedAllReduce:
             return
         for b in range(len(self.buckets)):
             self._launch(b)
+        if self.lane_fill is not None:
+            # the caller has joined every stream that ran part of the backward with the current one: whatever any
+            # recurrence of this step did to the fault word is visible to the fill kernel
+            if self.lane is None:
+                self.lane = torch.zeros(4, device=self.flat.grad.device, dtype=torch.float32)
+            if self.flat.grad.is_cuda:
+                if self.comm_stream is None:
+                    self.comm_stream = torch.cuda.Stream(device=self.flat.grad.device)
+                cs = self.comm_stream
+                cs.wait_stream(torch.cuda.current_stream(self.flat.grad.device))
+                with torch.cuda.stream(cs):
+                    self.lane_fill(self.lane)
+                    self.works.append(dist.all_reduce(self.lane, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            else:
+                self.lane_fill(self.lane)
+                self.works.append(dist.all_reduce(self.lane, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         for w in self.works:
             w.wait()
         self.works = []

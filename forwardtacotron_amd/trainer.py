@@ -11,11 +11,18 @@ no SyncBN), every rank applies the identical Adam update.
 
 Recurrence faults.  The persistent recurrences poll other workgroups with bounded spins; a poll that runs out leaves
 garbage in that step's activations / gradients and sets the device's sticky fault word.  The clip kernel reads the word
-ON THE DEVICE: the Adam kernel then leaves parameters and moments untouched, the reported grad_norm is NaN, and
-`out['rnn_fault']` is 1.  The host learns about it without a per-step sync: the flag of every step is copied to pinned
-memory asynchronously and looked at when a later step (or `check()`) finds the copy complete.  Policy `on_rnn_fault`:
-'raise' (default) raises FtError; 'fallback' clears the word, switches the library to the per-step recurrence kernels
-and carries on (the faulted steps made no update; their BatchNorm running statistics and `step` increments remain).
+ON THE DEVICE: the Adam kernel then leaves parameters and moments untouched, the reported grad_norm is NaN,
+`out['rnn_fault']` is 1, and the buffers the forward pass updated in place -- BatchNorm running statistics,
+num_batches_tracked, `step` -- are put back from the snapshot taken at the start of the step (parallel.FlatBuffers,
+ft_guarded_restore): a faulted step leaves no trace in the model.  Under data parallelism the fault is made GLOBAL before
+anything is applied: every rank all-reduces a fault lane with its gradient buckets (parallel.BucketedAllReduce) and every
+rank skips alike (`rnn_fault` = 2 on the ranks that only heard of it) -- the faulting rank's garbage gradient has been
+summed into everybody's buckets by then.  The host learns about it without a per-step sync: the flag of every step is
+copied to pinned memory asynchronously and looked at when a later step (or `check()`) finds the copy complete; with more
+than one rank the flag of step s is consumed exactly at the start of step s + 2 on EVERY rank (a wait that is already
+over: the host is never two steps ahead of the device), so that all ranks rewind Adam's step count and switch kernels at
+the same step.  Policy `on_rnn_fault`: 'raise' (default) raises FtError; 'fallback' clears the word, switches the library
+to the per-step recurrence kernels and carries on.
 """
 import gc
 import os
@@ -27,9 +34,10 @@ import torch.distributed as dist
 from . import _lib
 from . import hip as H
 from . import ops
-from .parallel import BucketedAllReduce, FlatParams
+from .parallel import BucketedAllReduce, FlatBuffers, FlatParams
 
 _CU_LIMITED_STREAMS: Dict[tuple, 'torch.cuda.Stream'] = {}
+_WARNED_CUS = False
 
 DEFAULT_TRAIN_CFG = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss_factor=0.1,
                          pitch_zoneout=0.0, energy_zoneout=0.0, clip_grad_norm=1.0)
@@ -38,7 +46,12 @@ DEFAULT_TRAIN_CFG = dict(dur_loss_factor=0.1, pitch_loss_factor=0.1, energy_loss
 class TrainStep:
     def __init__(self, model: torch.nn.Module, lr: float, train_cfg: Optional[dict] = None,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, bucket_bytes: int = 24 << 20,
-                 on_rnn_fault: str = 'raise'):
+                 on_rnn_fault: str = 'raise', gc_freeze: Optional[bool] = None):
+        """gc_freeze: after the third step, move every object alive in the process out of Python's cyclic GC
+        (gc.freeze()).  A full collection walks all modules / parameters / caches -- 30-70 ms of host stall every ~25
+        steps with the GPU running dry (profiles/r02_per_step_ms.txt) -- but the freeze is PROCESS-WIDE, so it is the
+        application's decision: off unless asked for here or with FT_GC_FREEZE=1 (bench.py and tools/ ask for it);
+        close() undoes it."""
         self.model = model
         self.lr = float(lr)
         self.cfg = dict(DEFAULT_TRAIN_CFG)
@@ -49,6 +62,7 @@ class TrainStep:
         dev = self.flat.flat.device
         if dev.type != 'cuda':
             raise _lib.FtError('TrainStep needs the model on an MI355X (HIP) device')
+        self.bufs = FlatBuffers(model)
         self.exp_avg = torch.zeros_like(self.flat.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat)
         self.opt_step = 0
@@ -61,7 +75,8 @@ class TrainStep:
         self._fault_next = 0
         self.skipped_steps = 0          # optimizer steps the device skipped because of a recurrence fault
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.reducer = BucketedAllReduce(self.flat, process_group, bucket_bytes)
+        self.reducer = BucketedAllReduce(self.flat, process_group, bucket_bytes,
+                                         lane_fill=lambda lane: _lib.call('ft_fault_lane_set', lane.data_ptr(), H._stream()))
         # weight gradients are written straight into the flat buffer, the GEMM-shaped ones on a side stream
         # models with a recurrent trunk: 28 CUs per XCD by default (see _make_wgrad_stream); FT_WGRAD_CUS overrides
         self.wgrad_stream = self._make_wgrad_stream(dev, None if 'FT_WGRAD_CUS' in os.environ
@@ -74,7 +89,21 @@ class TrainStep:
         self.main_stream = (torch.cuda.Stream(device=dev, priority=-1)
                             if os.environ.get('FT_MAIN_PRIORITY', '1') == '1' else None)
         self._packs_base = 0
-        self._gc_frozen = os.environ.get('FT_GC_FREEZE', '1') != '1'
+        if gc_freeze is None:
+            gc_freeze = os.environ.get('FT_GC_FREEZE', '0') == '1'
+        self._gc_frozen = not gc_freeze         # "nothing left to do"
+        self._did_freeze = False
+
+    def close(self) -> None:
+        """Undoes what this object did to the process: unfreezes the cyclic GC (if it froze it) and breaks the
+        parameter -> hook -> reducer -> FlatParams -> parameter cycle so that a dropped TrainStep (and its flat gradient
+        and Adam moments on the device) can be collected."""
+        if self._did_freeze:
+            gc.unfreeze()
+            self._did_freeze = False
+        self._gc_frozen = True
+        self.reducer.close()
+        self.sink.on_write = None
 
     @staticmethod
     def _make_wgrad_stream(dev, n: Optional[int] = None) -> 'torch.cuda.Stream':
@@ -91,6 +120,18 @@ class TrainStep:
         if n is None:
             n = int(os.environ.get('FT_WGRAD_CUS', '0'))
         if n <= 0 or n >= 32:
+            return torch.cuda.Stream(device=dev)
+        # the mask layout (bit i = CU i/8 of XCD i%8) is that of a whole MI355X: 8 XCDs x 32 CUs.  On anything else (a
+        # DPX / CPX partition, another part) an ordinary stream is used -- unless FT_WGRAD_CUS asked for the mask by name
+        cus, is950 = ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            _lib.call('ft_device_info', ctypes.byref(cus), ctypes.byref(is950))
+        if (cus.value != 256 or not is950.value) and 'FT_WGRAD_CUS' not in os.environ:
+            global _WARNED_CUS
+            if not _WARNED_CUS:
+                _WARNED_CUS = True
+                import warnings
+                warnings.warn(f'weight-gradient stream: {cus.value} CUs visible (not a whole MI355X): no CU mask')
             return torch.cuda.Stream(device=dev)
         # one such stream per (device, n) and process, shared by every TrainStep and never destroyed: the caching
         # allocator may still record events on it for tensors that outlive the TrainStep which used it
@@ -176,7 +217,9 @@ class TrainStep:
         """batch: device tensors with the ForwardCollator layout (utils/dataset.py:239-263).  Returns the
         loss terms and the pre-clip gradient norm as device scalars (no host sync in here except the
         LengthRegulator's output-size read, which the reference has too)."""
-        self._poll_faults(wait=False)       # a fault of an EARLIER step whose flag has reached the host by now
+        # a fault of an EARLIER step whose flag has reached the host by now; with several ranks: exactly the flags of the
+        # steps up to two back, on every rank (see the module docstring)
+        self._poll_faults(wait=self.world > 1, upto=self.opt_step - 1 if self.world > 1 else None)
         if self.main_stream is None:
             return self._step(batch)
         # the step's critical path runs on a HIGH-priority stream: its bandwidth-bound kernels (BatchNorm statistics,
@@ -196,6 +239,9 @@ class TrainStep:
         model.train()
         if not self.flat.attached():
             self.flat.attach()
+        if not self.bufs.attached():
+            self.bufs.attach()
+        self.bufs.snapshot()                # what a faulted step is rolled back to (optimizer_step)
         c = self.cfg
         pitch_target = batch['pitch'].detach().clone()
         energy_target = batch['energy'].detach().clone()
@@ -339,6 +385,7 @@ class TrainStep:
             gc.collect()
             gc.freeze()
             self._gc_frozen = True
+            self._did_freeze = True
         return out
 
     # -- recurrence-fault surfacing (no per-step host sync) ------------------------------------------------
@@ -356,14 +403,16 @@ class TrainStep:
         slot[2] = self.opt_step
 
     def _consume(self, slot) -> None:
-        step_no, bad = slot[2], float(slot[0][0]) != 0.0
+        step_no, flag = slot[2], float(slot[0][0])
         slot[2] = None
-        if bad:
-            self._handle_fault(step_no)
+        if flag != 0.0:
+            self._handle_fault(step_no, remote=flag == 2.0)
 
-    def _poll_faults(self, wait: bool) -> None:
+    def _poll_faults(self, wait: bool, upto: Optional[int] = None) -> None:
         for slot in sorted((s for s in self._fault_slots if s[2] is not None), key=lambda s: s[2]):
             if slot[2] is None:             # an earlier slot's fault handling already dealt with everything pending
+                continue
+            if upto is not None and slot[2] > upto:
                 continue
             if wait:
                 slot[1].synchronize()
@@ -371,7 +420,7 @@ class TrainStep:
                 continue
             self._consume(slot)
 
-    def _handle_fault(self, first_bad_step: int) -> None:
+    def _handle_fault(self, first_bad_step: int, remote: bool = False) -> None:
         # the fault word is sticky: every optimizer step from `first_bad_step` on was skipped on the device
         torch.cuda.synchronize()
         self.skipped_steps += self.opt_step - (first_bad_step - 1)
@@ -382,8 +431,10 @@ class TrainStep:
             H.check_rnn_status(clear=True)
         except _lib.FtError:
             pass
-        msg = (f'persistent recurrence timed out in optimizer step {first_bad_step}: that update (and every later one) '
-               f'was skipped on the device, parameters are intact')
+        where = 'on ANOTHER rank ' if remote else ''
+        msg = (f'persistent recurrence timed out {where}in optimizer step {first_bad_step}: that update (and every later '
+               f'one) was skipped on the device{" of every rank" if self.world > 1 else ""}; parameters, Adam moments, '
+               f'BatchNorm running statistics and step counters are intact')
         if self.on_rnn_fault == 'fallback':
             _lib.query('ft_rnn_set_persistent', 0)
             import warnings
@@ -399,8 +450,17 @@ class TrainStep:
         f = self.flat
         ws = H.workspace(_lib.query('ft_grad_norm_workspace'), f.flat.device)
         max_norm = self.cfg.get('clip_grad_norm') or 0.0
+        lane = self.reducer.lane            # the all-reduced fault lane (None: no process group)
         _lib.call('ft_clip_grad_norm', f.grad.data_ptr(), f.total, float(max_norm), 1.0 / self.world,
-                  self.coef.data_ptr(), ws.data_ptr(), ws.numel(), H._stream())
+                  lane.data_ptr() if lane is not None else None, self.coef.data_ptr(), ws.data_ptr(), ws.numel(),
+                  H._stream())
+        b = self.bufs                       # a faulted step leaves no trace in the forward-updated buffers either
+        if b.stats.numel():
+            _lib.call('ft_guarded_restore', b.stats.data_ptr(), b.stats_snap.data_ptr(), b.stats.numel(),
+                      self.coef.data_ptr(), H._stream())
+        if b.counts.numel():
+            _lib.call('ft_guarded_restore', b.counts.data_ptr(), b.counts_snap.data_ptr(), 2 * b.counts.numel(),
+                      self.coef.data_ptr(), H._stream())
         self.opt_step += 1
         _lib.call('ft_adam_step', f.flat.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
                   self.exp_avg_sq.data_ptr(), f.total, self.lr, self.betas[0], self.betas[1], self.eps,

@@ -21,7 +21,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define FWDTACO_ABI_VERSION 2
+#define FWDTACO_ABI_VERSION 3
 
 #ifdef __cplusplus
 extern "C" {
@@ -398,12 +398,22 @@ int ft_bt_transpose(const float* src, float* dst, int B, int T, int C, int dst_t
 /* ---- clip_grad_norm_ + torch.optim.Adam (trainer/forward_trainer.py:95-99 ; train_forward.py:76) ------ */
 /* over FLAT fp32 buffers (all parameters back to back, 16-B aligned).  coef_and_norm holds FOUR floats:
  * [0] = pre_scale * min(1, max_norm/(norm+1e-6)), [1] = norm = pre_scale*||grads||_2 (pre_scale = 1/world_size when
- * the buffer holds an all-reduced SUM), [2] = 1 if the device's recurrence-fault word is set (then [0] = 0, [1] = NaN and
- * ft_adam_step leaves params / moments untouched), [3] = 0; max_norm <= 0 disables clipping.  Stays on device: no host
- * sync. */
+ * the buffer holds an all-reduced SUM), [2] = 1 if the device's recurrence-fault word is set, 2 if only fault_lane says
+ * so (then [0] = 0, [1] = NaN and ft_adam_step leaves params / moments untouched), [3] = 0; max_norm <= 0 disables
+ * clipping.  Stays on device: no host sync.
+ * Data parallelism (new work: the reference is single device, train_forward.py:70): a recurrence fault must be GLOBAL --
+ * the faulting rank's garbage gradient is summed into every rank's buckets.  ft_fault_lane_set writes this device's fault
+ * word as 1.0 / 0.0 into lane[0] (lane = 4 floats, 16-B aligned; [1..3] = 0); the caller SUM-all-reduces the lane with the
+ * gradient and hands it to ft_clip_grad_norm as fault_lane (NULL: single device): a non-zero lane[0] skips the update on
+ * every rank alike. */
 size_t ft_grad_norm_workspace(void);
-int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scale, float* coef_and_norm,
-                      void* workspace, size_t workspace_bytes, void* stream);
+int ft_clip_grad_norm(const float* grads, long n, float max_norm, float pre_scale, const float* fault_lane,
+                      float* coef_and_norm, void* workspace, size_t workspace_bytes, void* stream);
+int ft_fault_lane_set(float* lane, void* stream);
+/* dst[0..nwords) <- snapshot (4-byte words) iff coef[2] != 0 (ft_clip_grad_norm's record): puts the buffers a forward
+ * pass updates in place (BatchNorm running_mean / running_var / num_batches_tracked, forward_tacotron.py:101,126-127
+ * `step`) back to their values from before a faulted step; a no-op launch otherwise */
+int ft_guarded_restore(void* dst, const void* snapshot, long nwords, const float* coef, void* stream);
 /* Adam, torch defaults semantics (no weight decay / amsgrad): g = grads*coef[0]; step counts from 1; coef (may be NULL)
  * is ft_clip_grad_norm's 4-float record: a set [2] skips the update */
 int ft_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,

@@ -142,3 +142,98 @@ def test_train_step_over_rccl_one_rank_group(bucket_bytes):
     assert norms == want_norms
     for k, v in m.state_dict().items():
         assert torch.equal(v.cpu(), torch.from_numpy(sd[k])), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# a recurrence fault on ONE rank must be acted on by EVERY rank
+# ---------------------------------------------------------------------------------------------------
+def _fault_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from forwardtacotron_amd import _lib, hip as H
+    from forwardtacotron_amd.model import ForwardTacotron
+    from forwardtacotron_amd.trainer import TrainStep
+    from oracle.ft_oracle import synthetic_batch
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    cfg = dict(TINY, rnn_dims=32, postnet_dims=32, durpred_rnn_dims=16)    # persistent-eligible recurrences
+    torch.manual_seed(3)
+    m = ForwardTacotron(**cfg).cuda()
+    ts = TrainStep(m, lr=1e-3, train_cfg=TRAIN_CFG, bucket_bytes=4096)
+    batch = synthetic_batch(B=4, Tmax=12, n_mels=10, max_dur=5, seed=50 + rank)
+    dev = lambda: {k: v.clone().cuda() for k, v in batch.items()}
+    res = {'rank': rank}
+    ts.step(dev())
+    torch.cuda.synchronize()
+    before = (ts.flat.flat.clone(), ts.exp_avg.clone(), ts.exp_avg_sq.clone(), ts.bufs.stats.clone(), ts.bufs.counts.clone())
+    n0 = H.rnn_counters()[0]
+    if rank == 1:
+        _lib.lib().ft_rnn_set_max_spins(-1)                  # every poll of THIS rank's persistent recurrences fails
+    try:
+        out = ts.step(dev())
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().ft_rnn_set_max_spins(0)
+    res['persistent_ran'] = H.rnn_counters()[0] > n0
+    res['flag'] = float(out['rnn_fault'])
+    res['norm_nan'] = bool(torch.isnan(out['grad_norm']))
+    after = (ts.flat.flat, ts.exp_avg, ts.exp_avg_sq, ts.bufs.stats, ts.bufs.counts)
+    res['untouched'] = all(torch.equal(a, b) for a, b in zip(before, after))
+    out = ts.step(dev())                                      # the word is sticky on rank 1: skipped again, everywhere
+    torch.cuda.synchronize()
+    res['flag2'] = float(out['rnn_fault'])
+    res['untouched2'] = all(torch.equal(a, b) for a, b in zip(before, after))
+    try:
+        ts.step(dev())                                        # the faulted step's flag is two steps old: every rank raises
+        res['raised'] = None
+    except _lib.FtError as e:
+        res['raised'] = str(e)
+    res['opt_step'], res['skipped'] = ts.opt_step, ts.skipped_steps
+    norms = []
+    for _ in range(2):                                        # ... and both carry on, identically
+        out = ts.step(dev())
+        norms.append(float(out['grad_norm']))
+    ts.check()
+    torch.cuda.synchronize()
+    res['norms'] = norms
+    res['flag3'] = float(out['rnn_fault'])
+    res['sd'] = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    res['moments'] = (ts.exp_avg.cpu().numpy(), ts.exp_avg_sq.cpu().numpy())
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_recurrence_fault_on_one_rank_is_global():
+    """Two ranks (one GPU, gloo), rank 1's persistent recurrences forced to time out in the second step.  Rank 1's garbage
+    gradient is summed into both ranks' buckets; the fault lane (all-reduced behind the buckets) makes BOTH ranks skip the
+    update on the device: parameters, Adam moments, BatchNorm statistics and counters bit-unchanged on both, rnn_fault = 1
+    on the faulting rank and 2 on the other; both raise at the start of the same later step, both rewind Adam's step
+    count alike, and the steps after that leave both ranks with bit-identical parameters and moments."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fault_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t['rank'])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert r1['persistent_ran'], 'the persistent form must have run on the faulting rank (else this tests nothing)'
+    assert r1['flag'] == 1.0 and r0['flag'] == 2.0
+    for r in res:
+        assert r['norm_nan'] and r['untouched'] and r['untouched2'], r['rank']
+        assert r['flag2'] != 0.0
+        assert r['raised'] is not None and 'timed out' in r['raised'], r['rank']
+        assert r['opt_step'] == 1 and r['skipped'] == 2, (r['opt_step'], r['skipped'])   # rewound to the last real update
+        assert r['flag3'] == 0.0
+    assert 'ANOTHER rank' in r0['raised'] and 'ANOTHER rank' not in r1['raised']
+    assert r0['norms'] == r1['norms']
+    for k in r0['sd']:
+        if r0['sd'][k].dtype.kind == 'f' and 'running_' in k:
+            continue                                            # BatchNorm statistics are per rank (no SyncBN)
+        assert (r0['sd'][k] == r1['sd'][k]).all(), k
+    assert (r0['moments'][0] == r1['moments'][0]).all() and (r0['moments'][1] == r1['moments'][1]).all()

@@ -227,9 +227,17 @@ def test_recurrence_fault_skips_the_update_and_raises():
     out = ts.step(dev()); out2 = ts2.step(dev())
     ts.check(); ts2.check()
     assert float(out['rnn_fault']) == 0.0
-    # BatchNorm running stats saw one extra (skipped) forward in `m`; trainable parameters must agree with the twin
+    # the faulted step left no trace: parameters AND the forward-updated buffers (BatchNorm running statistics,
+    # num_batches_tracked, step) agree with the twin that never ran it (they used to keep the faulted forward)
     assert maxdiff(ts.flat.flat.cpu(), ts2.flat.flat.cpu()) < 1e-6
     assert abs(float(out['grad_norm']) - float(out2['grad_norm'])) < 1e-5
+    sd, sd2 = m.state_dict(), twin.state_dict()
+    for k in sd:
+        if sd[k].dtype.is_floating_point:
+            assert bool(torch.isfinite(sd[k]).all()), k
+            assert maxdiff(sd[k].cpu(), sd2[k].cpu()) < 1e-6, k
+        else:
+            assert torch.equal(sd[k].cpu(), sd2[k].cpu()), k
 
 
 def test_recurrence_fault_fallback_policy_continues_on_per_step_kernels():
@@ -237,6 +245,8 @@ def test_recurrence_fault_fallback_policy_continues_on_per_step_kernels():
     from forwardtacotron_amd.trainer import TrainStep
     from oracle import ft_oracle as O
     m, cfg = _smoke_model()
+    twin, _ = _smoke_model()
+    twin.load_state_dict(m.state_dict())
     batch = O.synthetic_batch(B=4, Tmax=12, n_mels=10, max_dur=5, seed=1)
     dev = lambda: {k: v.clone().cuda() for k, v in batch.items()}
     ts = TrainStep(m, lr=1e-3, train_cfg=TRAIN_CFG, on_rnn_fault='fallback')
@@ -256,6 +266,18 @@ def test_recurrence_fault_fallback_policy_continues_on_per_step_kernels():
         assert H.rnn_counters()[0] == n0, 'per-step kernels expected after the fallback'
         assert float(out['rnn_fault']) == 0.0 and bool(torch.isfinite(out['grad_norm']))
         assert ts.opt_step == 1 and ts.skipped_steps == 1
+        # forced fault + fallback: running statistics equal those of a clean twin that took the one real step on the
+        # same (per-step) kernels, and are finite
+        ts2 = TrainStep(twin, lr=1e-3, train_cfg=TRAIN_CFG)
+        ts2.step(dev())
+        ts2.check()
+        sd, sd2 = m.state_dict(), twin.state_dict()
+        for k in sd:
+            if 'running_' in k:
+                assert bool(torch.isfinite(sd[k]).all()), k
+                assert maxdiff(sd[k].cpu(), sd2[k].cpu()) < 1e-6, k
+            elif not sd[k].dtype.is_floating_point:
+                assert torch.equal(sd[k].cpu(), sd2[k].cpu()), k
     finally:
         _lib.lib().ft_rnn_set_persistent(1)
 

@@ -68,7 +68,7 @@ def main():
     dur0 = batch['dur'].clone()
 
     if args.mode == 'train':
-        ts = TrainStep(model, lr=5e-5, train_cfg=dict(data.SINGLESPEAKER_TRAIN, pitch_cond_loss_factor=0.1))
+        ts = TrainStep(model, lr=5e-5, train_cfg=dict(data.SINGLESPEAKER_TRAIN, pitch_cond_loss_factor=0.1), gc_freeze=True)
 
         def step():
             batch['dur'].copy_(dur0)
