@@ -16,7 +16,8 @@ from typing import Dict, List, Tuple
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libfwdtaco_hip.so')
+# FT_LIB: another build of the same ABI (same-box A/B of kernel variants, lab/ only)
+LIB_PATH = os.environ.get('FT_LIB') or os.path.join(HERE, 'libfwdtaco_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(HERE), 'include', 'fwdtaco_hip.h')
 
 _SCALARS = {

@@ -106,7 +106,10 @@ struct Geom {
   unsigned max_spins;                  // bound of every arrival poll (ft_rnn_set_max_spins; tests force timeouts with it)
   int local_ok;                        // groups are XCD-slot aligned: the XCD-local hand-off may be used if placement agrees
   int gran;                            // XCD-local hand-off by granules where the kernel has them (FT_RNN_GRANULES=0: flag words)
+  int fast;                            // cell update with the hardware exp / rcp forms (FT_RNN_FAST_CELL)
 };
+__device__ __forceinline__ float sig_(float x, bool fast) { return fast ? ft_sigmoid_fast(x) : ft_sigmoid(x); }
+__device__ __forceinline__ float tanh_(float x, bool fast) { return fast ? ft_tanh_fast(x) : ft_tanh(x); }
 
 // sticky per-device fault word (one 128-B line of its own): set by any workgroup whose poll ran out, cleared only by
 // ft_rnn_status; read on the device by the optimizer kernels (ft_optim.hip) through ft_rnn_fault_word().  Words 8 / 9
@@ -235,18 +238,17 @@ __device__ __forceinline__ bool decode(const Geom& g, int& d, int& bgp, int& chu
 
 // ---------------------------------------------------------------------------------------------------
 // forward: workgroup = 16 batch rows x UB hidden units (all G gates = G*UB/16 column tiles), K = H over NW waves.
-// UB = 8 (the UB = 16 instantiation for the 512-wide LSTM -- 32 workgroups per group, one XCD -- exists but loses to
-// register spills, see fwd_persistent)
+// UB = 8, or 16 for the 512-wide LSTM (32 workgroups per group = one XCD) and the 256-wide GRU: see fwd_persistent
 // ---------------------------------------------------------------------------------------------------
 template <int G, int NW, bool B3, int UB, int BC>
-__global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_kernel(RnnFwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                      unsigned* fault, unsigned xb_bytes) {
   // UB hidden units (all G gates) per workgroup: G*UB columns = NT tiles of 16; cell waves = UB / 4 (one [16][4]
   // exchange block each)
   // BC = 32-k blocks of W_hh a wave keeps resident (bf16-split form): 1, 2 or 4, sized by the host to ceil(H/32 / NW)
   constexpr int NT = (G * UB + 15) / 16, BCH = BC, CW = UB / 4;
-  // granule hand-off (XCD-local mode) only where its buffers fit the register budget of two workgroups per CU: the
-  // 4-block form (LSTM-512 on 4 waves) keeps the flag words instead
+  // granule hand-off (XCD-local mode): two blocks of granules in flight (32 registers) whatever BC is; the 4-block form
+  // (LSTM-512 on 4 waves) takes it too since round 3 (FT_RNN_GRAN4=0: flag words)
   constexpr bool GRAN = B3 && BC <= 2;
   static_assert(UB % 4 == 0 && CW <= NW, "cell waves");
   // partial tiles, double-buffered by step parity: in XCD-local mode no barrier separates a step's readers (cell
@@ -362,44 +364,20 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
       }
     };
     const bool gl = local;              // protocol of THIS step's operands (the mode may change below, at s == 1)
-    if (s > 0 && gl && GRAN && geo.gran) {
-      // XCD-local, bf16-split: granules (file header).  Block c+1 is requested before block c is consumed; a block whose
-      // tags are not all the awaited ones is re-loaded until they are.
-      if constexpr (GRAN) {
-        const unsigned want_hi = ((unsigned)s & 0xFFFFu) << 16;
-        const unsigned gbase = (unsigned)(((long)2 * par_floats * 4) + ((long)((s - 1) & 1) * par_floats + base_floats) * 8);
-        auto offs = [&](int c, unsigned& oa, unsigned& ob) {
-          const long quad = 8 * (kb0 + c) + 2 * q;
-          oa = gbase + (unsigned)((quad * MB + l15) * 4 * 8);
-          ob = gbase + (unsigned)(((quad + 1) * MB + l15) * 4 * 8);
-        };
-        Gran gr[2];
-        unsigned oa, ob;
-        if (kb0 < kb1) {
-          offs(0, oa, ob);
-          gran_load(gr[0], rs, oa, ob);
-        }
-        bool ok = true;
-#pragma unroll
-        for (int c = 0; c < BCH; ++c)
-          if (kb0 + c < kb1) {
-            if (c + 1 < BCH && kb0 + c + 1 < kb1) {
-              unsigned na, nb;
-              offs(c + 1, na, nb);
-              gran_load(gr[(c + 1) & 1], rs, na, nb);
-            }
-            offs(c, oa, ob);
-            ok = gran_wait(gr[c & 1], rs, oa, ob, want_hi, geo.max_spins) && ok;
-            bf16x8 a3[3];
-            gran_unpack(gr[c & 1], a3);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) mfma6(a3, bw[nt][c], acc[nt]);
-          }
-        if (!ok && lane == 0) s_fail = 1;
-      }
-      request_xn();
-    } else if (s > 0) {
-      if (gl) {          // XCD-local, f32 MFMA form: flag words; every wave waits for the producers of its own slice
+    // granule mode of this step (wave-uniform): XCD-local, bf16-split (file header).  Block c+1 is requested before
+    // block c is consumed; a block whose tags are not all the awaited ones is re-loaded until they are.  The MFMA code
+    // below is shared with the fp32-exchange forms (one site per (block, tile): two sites made hipcc hold W_hh twice).
+    const bool gm = GRAN && s > 0 && gl && geo.gran;
+    const unsigned want_hi = ((unsigned)s & 0xFFFFu) << 16;
+    const unsigned gbase = (unsigned)(((long)2 * par_floats * 4) + ((long)((s - 1) & 1) * par_floats + base_floats) * 8);
+    auto goffs = [&](int c, unsigned& oa, unsigned& ob) {
+      const long quad = 8 * (kb0 + c) + 2 * q;
+      oa = gbase + (unsigned)((quad * MB + l15) * 4 * 8);
+      ob = gbase + (unsigned)(((quad + 1) * MB + l15) * 4 * 8);
+    };
+    Gran gr[2];
+    if (s > 0 && !gm) {
+      if (gl) {          // XCD-local, flag words: every wave waits for the producers of its own slice
         if (!poll_flag(pollf, (unsigned)s, geo.max_spins) && lane == 0) s_fail = 1;
       } else {
         if (wave == 0) {
@@ -420,6 +398,8 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
           if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);    // statistics: groups per mode
         }
       }
+    }
+    if (s > 0) {
       const long rbase = (long)((s - 1) & 1) * par_floats + base_floats;
       if constexpr (!B3) {
 #pragma unroll
@@ -436,22 +416,50 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
             for (int nt = 0; nt < NT; ++nt) mfma4(av[c], bv[nt][c], acc[nt]);
           }
       } else {
-#pragma unroll
-        for (int c = 0; c < BCH; ++c)
-          if (kb0 + c < kb1) {                      // lane (row l15, q): k = 32 blk + 8 q .. +7 = two exchange quads
-            const long quad = 8 * (kb0 + c) + 2 * q;
-            aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
-            aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
+        if (gm) {
+          if constexpr (GRAN) {
+            if (kb0 < kb1) {
+              unsigned oa, ob;
+              goffs(0, oa, ob);
+              gran_load(gr[0], rs, oa, ob);
+            }
           }
-        request_xn();
+        } else {
+#pragma unroll
+          for (int c = 0; c < BCH; ++c)
+            if (kb0 + c < kb1) {                      // lane (row l15, q): k = 32 blk + 8 q .. +7 = two exchange quads
+              const long quad = 8 * (kb0 + c) + 2 * q;
+              aw[c][0] = ld_sc1_b128(rs, (unsigned)((rbase + (quad * MB + l15) * 4) * 4));
+              aw[c][1] = ld_sc1_b128(rs, (unsigned)((rbase + ((quad + 1) * MB + l15) * 4) * 4));
+            }
+          request_xn();
+        }
+        bool ok = true;
 #pragma unroll
         for (int c = 0; c < BCH; ++c)
           if (kb0 + c < kb1) {
             bf16x8 a3[3];
-            split8(aw[c][0], aw[c][1], a3[0], a3[1], a3[2]);
+            if (gm) {
+              if constexpr (GRAN) {
+                unsigned oa, ob;
+                if (c + 1 < BCH && kb0 + c + 1 < kb1) {
+                  goffs(c + 1, oa, ob);
+                  gran_load(gr[(c + 1) & 1], rs, oa, ob);
+                }
+                goffs(c, oa, ob);
+                ok = gran_wait(gr[c & 1], rs, oa, ob, want_hi, geo.max_spins) && ok;
+                gran_unpack(gr[c & 1], a3);
+              }
+            } else {
+              split8(aw[c][0], aw[c][1], a3[0], a3[1], a3[2]);
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) mfma6(a3, bw[nt][c], acc[nt]);
           }
+        if (gm) {
+          if (!ok && lane == 0) s_fail = 1;
+          request_xn();
+        }
       }
     }
     if (s == 0) request_xn();
@@ -474,19 +482,19 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_fwd_persist_kernel(RnnFwdArgs 
         hp[g] = v + bg[g];
       }
       if (G == 3) {
-        const float r = ft_sigmoid(xg[0] + hp[0]);
-        const float z = ft_sigmoid(xg[1] + hp[1]);
-        const float n = ft_tanh(xg[2] + r * hp[2]);
+        const float r = sig_(xg[0] + hp[0], geo.fast);
+        const float z = sig_(xg[1] + hp[1], geo.fast);
+        const float n = tanh_(xg[2] + r * hp[2], geo.fast);
         hnew = (1.f - z) * n + z * hprev;
         sg[0] = r; sg[1] = z; sg[2] = n; sg[3] = hp[2];
       } else {
-        const float ig = ft_sigmoid(xg[0] + hp[0]);
-        const float fg = ft_sigmoid(xg[1] + hp[1]);
-        const float gg = ft_tanh(xg[2] + hp[2]);
-        const float og = ft_sigmoid(xg[G - 1] + hp[G - 1]);
+        const float ig = sig_(xg[0] + hp[0], geo.fast);
+        const float fg = sig_(xg[1] + hp[1], geo.fast);
+        const float gg = tanh_(xg[2] + hp[2], geo.fast);
+        const float og = sig_(xg[G - 1] + hp[G - 1], geo.fast);
         cnew = fg * cprev + ig * gg;
         cprev = cnew;
-        hnew = og * ft_tanh(cnew);
+        hnew = og * tanh_(cnew, geo.fast);
         sg[0] = ig; sg[1] = fg; sg[2] = gg; sg[3] = og;
       }
       hprev = hnew;
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
       } else {
         const float dh = dov + rec;
         const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
-        const float tc = ft_tanh(cc);
+        const float tc = tanh_(cc, geo.fast);
         const float dc = dh * og * (1.f - tc * tc) + carry;
         dgx[0] = dc * gg * ig * (1.f - ig);
         dgx[1] = dc * prev * fg * (1.f - fg);
@@ -1004,7 +1012,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
       } else {
         const float dh = dov + rec;
         const float ig = gv[0], fg = gv[1], gg = gv[2], og = gv[3];
-        const float tc = ft_tanh(cc);
+        const float tc = tanh_(cc, geo.fast);
         const float dc = dh * og * (1.f - tc * tc) + carry;
         dgx[0] = dc * gg * ig * (1.f - ig);
         dgx[1] = dc * prev * fg * (1.f - fg);
@@ -1289,6 +1297,7 @@ double plan_launch(KernelT kernel, int block, Geom& geo, int& grid, hipStream_t 
     geo.xcd_off = cand[i].xcd_off;
     geo.local_ok = cand[i].aligned && env_int("FT_RNN_LOCAL", 1);
     geo.gran = env_int("FT_RNN_GRANULES", 1);
+    geo.fast = env_int("FT_RNN_FAST_CELL", 1);
     return d;
   }
   ++g_n_refused;
@@ -1300,6 +1309,7 @@ int launch_fwd_persist(const RnnFwdArgs& a, Geom geo, const PersistWs& p, hipStr
   int grid = 0;
   const double cus = plan_launch(ft_rnn_fwd_persist_kernel<G, NW, B3, UB, BC>, NW * 64, geo, grid, stream);
   if (cus < 0.0) return -1;
+  if (BC > 2 && !env_int("FT_RNN_GRAN4", 1)) geo.gran = 0;
   (void)hipMemsetAsync(p.cnt, 0, p.total_bytes, stream);
   hipLaunchKernelGGL((ft_rnn_fwd_persist_kernel<G, NW, B3, UB, BC>), dim3(grid), dim3(NW * 64), 0, stream, a, geo, p.xb,
                      p.cnt, ft_rnn_fault_word(), (unsigned)p.xb_bytes);
@@ -1314,17 +1324,19 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   if (!a.vec || H % 16 != 0) return -1;
   const int ngroups = H / 16;
   int NW = ngroups > 16 ? 8 : 4;
-  // 4-wave workgroups for the widest layer too (H = 512: each wave keeps 4 of the 16 k-blocks): 256-thread workgroups
-  // run two per CU, so the 64 workgroups of a (direction, batch group) group fit ONE XCD and hand over through its L2
-  if (NW == 8 && G == 4 && H % 32 == 0 && ft_cdiv(H / 32, 4) <= 4 && env_int("FT_RNN_FWD_NW4", 1)) NW = 4;
+  // The 512-wide LSTM: a (direction, batch group) group must fit ONE XCD to hand over through its L2, i.e. at most 32
+  // workgroup-CUs.  Two forms do: (a) 16 units per 8-wave workgroup (32 workgroups, one per CU; 2 resident k-blocks per
+  // wave, granule hand-off) -- every CU then pulls the group's h once per step instead of twice (two 8-unit workgroups
+  // per CU: 64 KB per CU and step through one 64 B/clk path) -- and (b) 8 units per 4-wave workgroup (64 workgroups, two
+  // per CU; 4 resident blocks per wave, flag words).  Round 2 measured (a) at 5.65 us per step against 3.77: it spilled
+  // 57 registers.  With ONE MFMA site per (block, tile) for all hand-off protocols (round 3) it spills 4 and runs 3.51
+  // against 3.88 in isolation, 22.8 -> 22.3 ms per train step (profiles/r03_rnn_ab.txt).  FT_RNN_FWD_UB16=0: form (b).
+  const bool wide = NW == 8 && G == 4 && H / 8 > 32 && H % 32 == 0 && ft_cdiv(H / 32, 8) <= 2 && env_int("FT_RNN_B3", 1) &&
+                    env_int("FT_RNN_FWD_UB16", 1);
+  if (!wide && NW == 8 && G == 4 && H % 32 == 0 && ft_cdiv(H / 32, 4) <= 4 && env_int("FT_RNN_FWD_NW4", 1)) NW = 4;
   if (ft_cdiv(ngroups, NW) > GCH) return -1;
   const int bpw = H % 32 == 0 ? ft_cdiv(H / 32, NW) : 99;                 // 32-k blocks per wave in the split form
   const bool b3 = bpw <= 4 && env_int("FT_RNN_B3", 1);                    // matmul on the bf16 pipe (exact split)
-  // 16 units per workgroup where 8 would need more than the 32 workgroups per group one XCD can host (H = 512): the
-  // group then fits one XCD and runs XCD-local -- but the kernel needs 256 registers per lane AND spills 57 dwords,
-  // measured 5.65 us/step against 3.77 for the 8-unit form on the agent-scope protocol (lab/rnn_step_us.py): off by
-  // default (FT_RNN_FWD_UB16=1 enables it), kept for the day the register diet succeeds
-  const bool wide = b3 && NW == 8 && G == 4 && H / 8 > 32 && H % 16 == 0 && bpw <= 2 && env_int("FT_RNN_FWD_UB16", 0);
   // GRU, H = 256 (the trunk's two GRUs; the postnet's runs 841 steps): 8 waves with ONE resident k-block each and 16
   // hidden units per workgroup -- 16 producers per group instead of 32, half the operand bytes per wave.  Same box,
   // us per step at T = 841 (lab/gru256_ab.py): 4 waves x 2 blocks x 8 units 2.03 | 8 x 1 x 8: 2.03-2.07 | 4 x 2 x 16:
@@ -1342,6 +1354,7 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.xcd_off = 0;
   geo.local_ok = 0;
   geo.gran = 0;
+  geo.fast = 0;
   a.s = 0;
   if (wide) return launch_fwd_persist<G, 8, true, 16, 2>(a, geo, p, stream);
   if constexpr (G == 3) {
@@ -1425,6 +1438,7 @@ int bwd_persistent(RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
   geo.xcd_off = 0;
   geo.local_ok = 0;
   geo.gran = 0;
+  geo.fast = 0;
   a.s = 0;
   {
     const int rc = bwd_persistent_rs<G>(a, geo, ws, ws_bytes, stream);
