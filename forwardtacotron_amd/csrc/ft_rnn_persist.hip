@@ -111,6 +111,27 @@ struct Geom {
 __device__ __forceinline__ float sig_(float x, bool fast) { return fast ? ft_sigmoid_fast(x) : ft_sigmoid(x); }
 __device__ __forceinline__ float tanh_(float x, bool fast) { return fast ? ft_tanh_fast(x) : ft_tanh(x); }
 
+// Diagnostic build only (hipcc -DFT_RNN_PROF, lab/build_prof.sh -> lab/libfwdtaco_prof.so, never the product library):
+// s_memtime stamps at the seams of a time step, summed per phase over the launch for two waves of one workgroup and read
+// back with ft_rnn_prof_read.  The stamps go to a buffer nothing else reads; no output depends on them.
+#ifdef FT_RNN_PROF
+__device__ unsigned long long g_prof[64];
+#define PROF_DECL unsigned long long pt_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pl_ = __builtin_amdgcn_s_memtime()
+#define PROF(i)                                              \
+  {                                                          \
+    const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+    pt_[i] += n_ - pl_;                                      \
+    pl_ = n_;                                                \
+  }
+#define PROF_DUMP(sel, slot)                                              \
+  if ((sel) && (threadIdx.x & 63) == 0)                                   \
+    for (int i_ = 0; i_ < 12; ++i_) g_prof[(slot) * 12 + i_] = pt_[i_]
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_DUMP(sel, slot)
+#endif
+
 // sticky per-device fault word (one 128-B line of its own): set by any workgroup whose poll ran out, cleared only by
 // ft_rnn_status; read on the device by the optimizer kernels (ft_optim.hip) through ft_rnn_fault_word().  Words 8 / 9
 // of the line count the groups that ran XCD-local / on the agent-scope protocol (ft_rnn_mode_counts).
@@ -873,8 +894,22 @@ template <int G, int NW, int NT>
 __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Geom geo, float* xb, unsigned* cnt,
                                                                 unsigned* fault, unsigned xb_bytes) {
   constexpr int ALD = 68;                             // LDS row stride of the local d(gates) tile [16][64]
-  constexpr int PC = NW * NT;                         // chunks per group = H / 16 (checked by the host)
+  constexpr int GWV = 4;                              // gathering waves = the cell waves
+  constexpr int TPW = NW * NT / GWV;                  // incoming tiles per gathering wave (chunks per group = NW * NT)
+  // PF: ONE wave beyond the cell waves (wave 4) fetches the NEXT step's saved activations for the cell threads, through
+  // LDS.  Those loads come from HBM (441 MB of saved gates at the benchmark shape, ~4000 cycles) and vector-memory
+  // operations complete in order -- per wave (vmcnt) and, as measured here, per CU: issued by the cell threads
+  // themselves, a step ahead (until round 3: 7 four-byte loads per lane, 448 line requests per step), they sat in front
+  // of the step's hand-off loads and of the vmcnt(0) before its flag store: 1.2 of the 4.0 us of an LSTM-512 step
+  // (lab/rnn_phase_prof.py: 4.37 -> 2.98 us without them); issued by other waves at the END of a step they still held up
+  // the cell waves' hand-off loads right behind them (4.2 us).  So: 7 coalesced 16-byte wave loads (112 line requests),
+  // issued right after the step's hand-off loads have landed (barrier A), a whole MFMA phase before the next ones.
+  constexpr bool PF = NW >= 8;
+  constexpr int NIN = 7;                              // gates[4], dout, c (LSTM), previous h (GRU) / c (LSTM)
   __shared__ __attribute__((aligned(16))) float adg2[2 * 16 * ALD];   // double-buffered by step parity
+  // per-wave partial sums of the incoming tiles (wave w adds the tiles of producers w*TPW .. w*TPW+TPW-1), [wave][unit][row]
+  __shared__ __attribute__((aligned(16))) float rsum[GWV * 256];
+  __shared__ float inb[PF ? 2 * NIN * 256 : 1];       // next-step inputs of the 256 cell threads, by step parity
   __shared__ int s_ok;
   int d, bgp, chunk, grp;
   if (!decode(geo, d, bgp, chunk, grp)) return;
@@ -919,9 +954,10 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
   }
   for (int i = tid; i < 2 * 16 * ALD; i += NW * 64) adg2[i] = 0.f;  // (GRU: k 48..63 stay zero)
 
-  // XCD-local mode: a cell wave needs the tile every producer chunk p computed for this consumer chunk; that tile came
-  // from producer wave chunk / NT -> flag NW*p + chunk/NT
-  const unsigned* pollf = (tid < 256 && lane < P) ? myflags + NW * lane + chunk / NT : nullptr;
+  // XCD-local mode: cell wave w gathers the tiles the producer chunks p = w*TPW + i (i < TPW) computed for this
+  // consumer chunk; such a tile came from producer wave chunk / NT -> flag NW*p + chunk/NT
+  const unsigned* pollf =
+      (wave < GWV && lane < TPW && wave * TPW + lane < P) ? myflags + NW * (wave * TPW + lane) + chunk / NT : nullptr;
 
   // ---- cell threads (first 256): thread = (unit cj, row ci), the order of an exchange block
   const int cj = tid >> 4, ci = tid & 15;
@@ -930,6 +966,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
   const bool cthr = sthr && cb < a.B;
   const int L = cthr ? clamp_len(a.lens, cb, T) : 0;
   float carry = 0.f;
+  // ---- fetching lanes (PF: wave 4): lane = (row fr, unit quad fq) -> 16 bytes = units u0 + 4 fq .. + 3 of row fr
+  const bool fwave = PF && wave == 4;
+  const int fr = lane >> 2, fq = lane & 3;
+  const int fb = b0 + fr;
+  const int FL = (fwave && fb < a.B) ? clamp_len(a.lens, fb, T) : 0;
 
   float gv[4] = {0.f, 0.f, 0.f, 0.f}, dov = 0.f, cc = 0.f, prev = 0.f;
   auto request = [&](int sn, float (&rgv)[4], float& rdo, float& rcc, float& rprev) {
@@ -954,10 +995,52 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
       }
     }
   };
-  request(0, gv, dov, cc, prev);
+  // PF: the fetching wave holds the inputs of the NEXT step in fv (requested behind barrier A of a step, stored to inb
+  // behind its own flag store at the end of that step); without PF the cell threads request their own, one step ahead
+  float4 fv[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) fv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int sn) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) fv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fwave && sn < FL) {
+      const int ct = d == 0 ? FL - 1 - sn : sn;
+      const int tprev = d == 0 ? ct - 1 : ct + 1;
+      const bool has_prev = tprev >= 0 && tprev < FL;
+      const long o = ((long)ct * a.B + fb) * ldo + (long)d * H + u0 + 4 * fq;
+      const long op = ((long)tprev * a.B + fb) * ldo + (long)d * H + u0 + 4 * fq;
+      const float* gs = a.gates + (((long)ct * a.B + fb) * a.ND + d) * 4 * H + u0 + 4 * fq;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fv[g] = *reinterpret_cast<const float4*>(gs + (long)g * H);
+      fv[4] = *reinterpret_cast<const float4*>(a.dout + o);
+      if (G == 3) {
+        if (has_prev) fv[6] = *reinterpret_cast<const float4*>(a.out + op);
+      } else {
+        fv[5] = *reinterpret_cast<const float4*>(a.cst + o);
+        if (has_prev) fv[6] = *reinterpret_cast<const float4*>(a.cst + op);
+      }
+    }
+  };
+  auto publish = [&](int sn) {            // fetching wave: fv -> inb[parity of step sn][value][unit][row]
+    if (fwave) {
+      float* ib = inb + (sn & 1) * (NIN * 256) + (4 * fq) * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) {
+        ib[i * 256] = fv[i].x; ib[i * 256 + 16] = fv[i].y; ib[i * 256 + 32] = fv[i].z; ib[i * 256 + 48] = fv[i].w;
+      }
+    }
+  };
+  if constexpr (PF) {
+    fetch(0);
+    publish(0);
+  } else {
+    request(0, gv, dov, cc, prev);
+  }
   __syncthreads();
+  PROF_DECL;
 
   for (int s = 0; s < T; ++s) {
+    PROF(0);
     const bool cact = cthr && s < L;
     const int ct = d == 0 ? L - 1 - s : s;
     float* adg = adg2 + (s & 1) * (16 * ALD);
@@ -984,19 +1067,46 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
           if (threadIdx.x == 0 && chunk == 0) atomicAdd(fault + (local ? 8 : 9), 1u);    // statistics: groups per mode
         }
       }
-      if (sthr) {       // the P partials of (row ci, unit cj), summed in producer order
-        const long rbase = (long)((s - 1) & 1) * par_floats + base_floats + (long)chunk * P * 256 + tid;
-        float v[PC];                                   // all loads in flight at once: one round trip
+      PROF(1);
+      // The P incoming tiles, [unit 16][row 16] floats each.  Each cell wave takes TPW of them with one 16-byte load per
+      // lane and tile (a whole 1-KB tile per wave instruction), adds them in producer order and leaves its partial in
+      // LDS; the cell threads then add the four partials in wave order.
+      if (wave < GWV) {
+        const long rbase = (long)((s - 1) & 1) * par_floats + base_floats + (long)chunk * P * 256 + 4 * lane;
+        float4 v[TPW];
 #pragma unroll
-        for (int i = 0; i < PC; ++i)
-          v[i] = __uint_as_float(
-              __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((rbase + (long)i * 256) * 4), 0, 16));
+        for (int i = 0; i < TPW; ++i) {
+          const int pp = wave * TPW + i;
+          v[i] = pp < P ? ld_sc1_b128(rs, (unsigned)((rbase + (long)pp * 256) * 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 acc4 = v[0];
 #pragma unroll
-        for (int i = 0; i < PC; ++i) rec += v[i];
+        for (int i = 1; i < TPW; ++i) {
+          acc4.x += v[i].x; acc4.y += v[i].y; acc4.z += v[i].z; acc4.w += v[i].w;
+        }
+        *reinterpret_cast<float4*>(rsum + wave * 256 + 4 * lane) = acc4;
+      }
+      __syncthreads();
+      if (sthr) {
+#pragma unroll
+        for (int w = 0; w < GWV; ++w) rec += rsum[w * 256 + tid];
       }
     }
-    float ngv[4], ndo, ncc, nprev;
-    request(s + 1, ngv, ndo, ncc, nprev);
+    if constexpr (PF) {
+      fetch(s + 1);     // (behind barrier A: this step's hand-off loads have landed)
+      if (sthr) {       // this step's saved activations, fetched during the previous step
+        const float* ib = inb + (s & 1) * (NIN * 256) + tid;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g] = ib[g * 256];
+        dov = ib[4 * 256]; cc = ib[5 * 256]; prev = ib[6 * 256];
+      }
+    }
+    float ngv[4] = {0.f, 0.f, 0.f, 0.f}, ndo = 0.f, ncc = 0.f, nprev = 0.f;
+    if constexpr (!PF) request(s + 1, ngv, ndo, ncc, nprev);
+#ifdef FT_RNN_PROF
+    asm volatile("" : "+v"(rec));
+#endif
+    PROF(2);
 
     float dgx[4] = {0.f, 0.f, 0.f, 0.f}, dgh2 = 0.f;
     if (cact) {
@@ -1026,7 +1136,9 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
 #pragma unroll
       for (int g = 0; g < G; ++g) adg[ci * ALD + g * 16 + cj] = (G == 3 && g == 2) ? dgh2 : dgx[g];
     }
+    PROF(3);
     __syncthreads();
+    PROF(4);
     if (s_fail) {                                          // a wave's poll ran out (XCD-local mode): leave together
       if (tid == 0) atomicExch(fault, 1u);
       return;
@@ -1040,7 +1152,10 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
         split8(*reinterpret_cast<const float4*>(ap), *reinterpret_cast<const float4*>(ap + 4), a3[blk][0], a3[blk][1],
                a3[blk][2]);
       }
+      PROF(5);
       const long wbase = (long)(s & 1) * par_floats + base_floats + (long)chunk * 256 + l15 * 16 + 4 * q;
+      // (issuing the products term-major over the NT independent tiles instead of tile by tile -- no chain of dependent
+      //  MFMAs -- measured 3.24 -> 3.37 us per step: the phase is not bound by the accumulator latency)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1054,7 +1169,9 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
           else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);            // write-through (sc1)
         }
       }
+      PROF(6);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PROF(7);
       if (lane == 0) {
         if (local)
           __hip_atomic_store(myflags + NW * chunk + wave, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1080,10 +1197,19 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_rs_kernel(RnnBwdArgs a, Ge
         dhh[0] = 0.f; dhh[H] = 0.f; dhh[2 * H] = 0.f;
       }
     }
+    if constexpr (PF) {
+      // fetching wave, behind its flag store (the vmcnt(0) in front of it covered the fetch): hand the inputs of step
+      // s + 1 to the cell threads
+      publish(s + 1);
+    } else {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gv[g] = ngv[g];
-    dov = ndo; cc = ncc; prev = nprev;
+      for (int g = 0; g < 4; ++g) gv[g] = ngv[g];
+      dov = ndo; cc = ncc; prev = nprev;
+    }
+    PROF(8);
   }
+  PROF_DUMP(grp == 0 && chunk == 3 && wave == 0, 0);
+  PROF_DUMP(grp == 0 && chunk == 3 && wave == 5, 1);
 }
 
 int g_persistent = -1;      // -1: take FT_RNN_PERSISTENT from the environment
@@ -1533,6 +1659,15 @@ int ft_rnn_mode_counts(long* xcd_local_groups, long* agent_scope_groups) {
   if (agent_scope_groups) *agent_scope_groups = v[1];
   return FT_OK;
 }
+
+#ifdef FT_RNN_PROF
+int ft_rnn_prof_read(unsigned long long* out, int n) {
+  return hipDeviceSynchronize() == hipSuccess &&
+                 hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * (n < 64 ? n : 64)) == hipSuccess
+             ? FT_OK
+             : FT_ERR_HIP;
+}
+#endif
 
 int ft_rnn_status(int clear) {
   unsigned* w = ft_rnn_fault_word();
