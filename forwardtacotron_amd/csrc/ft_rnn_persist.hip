@@ -360,7 +360,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
     for (int g = 0; g < G; ++g) xg[g] = xr[(long)g * H];
   }
 
+  PROF_DECL;
   for (int s = 0; s < T; ++s) {
+    PROF(0);
     const bool cact = cthr && s < L;
     const int ct = d == 0 ? s : L - 1 - s;
     float* red = red2 + (s & 1) * (NW * NT * 16 * RLD);
@@ -484,8 +486,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
       }
     }
     if (s == 0) request_xn();
+    PROF(1);
     store_partials<NT>(red, wave, lane, acc);
+    PROF(2);
     __syncthreads();
+    PROF(3);
     if (s_fail) {                                          // a wave's poll ran out (XCD-local mode): leave together
       if (tid == 0) atomicExch(fault, 1u);
       return;
@@ -528,6 +533,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
         __hip_atomic_store(xb + xe, hnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // write-through (sc1)
       }
     }
+    PROF(4);
     if (local && GRAN && geo.gran) {
       // granule {hi, mid, lo, tag = s + 1}: one 8-byte plain store per (row, unit), nothing else to signal.  EVERY row
       // slot is written every step -- rows beyond the batch and finished items as zeros -- because a consumer accepts a
@@ -555,6 +561,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
       if (tid == 0)
         __hip_atomic_fetch_add(mycnt + (chunk % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PROF(5);
     if (cact) {                                          // the step's outputs proper: off the recurrence's path
       const long o = ((long)ct * a.Bld + cb) * ldo + (long)d * H + cun;
       a.out[o] = hnew;
@@ -568,9 +575,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
       a.out[o] = 0.f;
       if (G == 4) a.cst[o] = 0.f;
     }
+    PROF(6);
 #pragma unroll
     for (int g = 0; g < G; ++g) xg[g] = xn[g];
+    PROF(7);
   }
+  PROF_DUMP(grp == 0 && chunk == 3 && wave == 0, 0);
+  PROF_DUMP(grp == 0 && chunk == 3 && wave == NW - 1, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -672,8 +683,10 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
     }
   };
   request(0, gv, dov, cc, prev);
+  PROF_DECL;
 
   for (int s = 0; s < T; ++s) {
+    PROF(0);
     const bool cact = cthr && s < L;
     const int ct = d == 0 ? L - 1 - s : s;
     float* red = red2 + (s & 1) * (NW * 16 * RLD);
@@ -776,8 +789,11 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
         }
       }
     }
+    PROF(1);
     store_partials<1>(red, wave, lane, acc);
+    PROF(2);
     __syncthreads();
+    PROF(3);
     if (s_fail) {                                          // a wave's poll ran out (XCD-local mode): leave together
       if (tid == 0) atomicExch(fault, 1u);
       return;
@@ -810,6 +826,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
         carry = dc * fg;
       }
     }
+    PROF(4);
     if (cthr) {
       // exchange: k = g*H + cun -> block k/4 = (g*H + u0)/4 + j4, row ci, slot jj ; a finished item's rows are
       // published as zeros for the workgroups that still multiply them
@@ -852,6 +869,7 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
       if (tid == 0)
         __hip_atomic_fetch_add(mycnt + (chunk % NSH) * CSTRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PROF(5);
     if (cact) {
       float* dx = a.dxp + ((long)ct * a.B + cb) * ldg + (long)d * K + cun;
 #pragma unroll
@@ -869,10 +887,14 @@ __global__ __launch_bounds__(NW * 64) void ft_rnn_bwd_persist_kernel(RnnBwdArgs 
         dhh[0] = 0.f; dhh[H] = 0.f; dhh[2 * H] = 0.f;
       }
     }
+    PROF(6);
 #pragma unroll
     for (int g = 0; g < 4; ++g) gv[g] = ngv[g];
     dov = ndo; cc = ncc; prev = nprev;
+    PROF(7);
   }
+  PROF_DUMP(grp == 0 && chunk == 3 && wave == 0, 0);
+  PROF_DUMP(grp == 0 && chunk == 3 && wave == 5, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
