@@ -165,6 +165,48 @@ int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, lo
   return ft_launch_gemm_rows(&b, 1, !w_transposed, (hipStream_t)stream);
 }
 
+// HighwayNetwork with the gate in the GEMM epilogue (ft_gemm.h: FtGemmBatch.hw_mode)
+int ft_highway_fwd(const float* x, const float* w12i, const float* b1, const float* b2, float* out, float* x12, int rows,
+                   int C, void* stream) {
+  FT_REQUIRE(C > 0 && C % 32 == 0, "highway_fwd: the fused form needs C %% 32 == 0 (C = %d)", C);
+  FT_REQUIRE(rows >= 0 && x && w12i && b1 && b2 && out, "highway_fwd: null operand");
+  if (rows == 0) return FT_OK;
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  FtGemmTask& t = b.t[0];
+  t.A = x; t.B = w12i; t.C = out;
+  t.lda = C; t.ldb = C; t.ldc = C;
+  t.M = rows; t.N = 2 * C; t.K = C; t.taps = 1;
+  t.amap = ft_rowmap_identity(rows);
+  t.cmap = ft_rowmap_identity(rows);
+  b.hw_mode = 1; b.hw_C = C; b.hw_x = x; b.hw_b1 = b1; b.hw_b2 = b2; b.hw_x12 = x12;
+  return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
+}
+
+int ft_highway_bwd_data(const float* d12, const float* w1, const float* w2, int w_transposed, float* dx, int rows, int C,
+                        const float* below_x12, const float* below_x, float* below_d12, void* stream) {
+  FT_REQUIRE(C > 0 && rows >= 0 && d12 && w1 && w2 && dx, "highway_bwd_data: bad arguments");
+  FT_REQUIRE((below_x12 != nullptr) == (below_x != nullptr) && (below_x != nullptr) == (below_d12 != nullptr),
+             "highway_bwd_data: below_x12 / below_x / below_d12 go together");
+  if (rows == 0) return FT_OK;
+  FtGemmBatch b;
+  memset(&b, 0, sizeof(b));
+  for (int i = 0; i < 2; ++i) {
+    FtGemmTask& t = b.t[i];
+    t.A = d12 + (long)i * C; t.B = i ? w2 : w1; t.C = dx;
+    t.lda = 2 * C; t.ldb = C; t.ldc = C;
+    t.M = rows; t.N = C; t.K = C; t.taps = 1;
+    t.amap = ft_rowmap_identity(rows);
+    t.cmap = ft_rowmap_identity(rows);
+    t.accumulate = 1;
+  }
+  b.chain = 2;
+  if (below_d12) {
+    b.hw_mode = 2; b.hw_C = C; b.hw_x = below_x; b.hw_x12 = const_cast<float*>(below_x12); b.hw_d12 = below_d12;
+  }
+  return ft_launch_gemm_rows(&b, 2, !w_transposed, (hipStream_t)stream);
+}
+
 // dx (+)= sum_i dy_i * w_i : several Linear layers that read the same input (highway W1/W2, the two directions of a
 // recurrence's input projection) hand their data gradients back in ONE chained launch
 int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,

@@ -153,6 +153,17 @@ __global__ void ft_highway_bwd_kernel(const float* __restrict__ dout, const floa
   dx[i] = d * (1.f - g);
 }
 
+// W1 | W2 ([C, C] each) -> their 32-row interleave [2C, C]: row n = row (n / 64) * 32 + n % 32 of W1 (n % 64 < 32) or W2
+// -- the B operand of the fused highway forward (ft_gemm.h: FtGemmBatch.hw_mode 1)
+__global__ void ft_highway_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                       float* __restrict__ out, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2L * C * C) return;
+  const int n = (int)(i / C), k = (int)(i - (long)n * C);
+  const int unit = (n >> 6) * 32 + (n & 31);
+  out[i] = ((n & 63) >> 5 ? w2 : w1)[(long)unit * C + k];
+}
+
 // ---- MaxPool1d(2,1,1)[:T] over channels-last: out[t] = max(x[t-1], x[t]) (first max wins ties) -----
 __global__ void ft_maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -548,6 +559,13 @@ int ft_highway_gate_bwd(const float* dout, const float* x12, const float* x, flo
   hipLaunchKernelGGL(ft_highway_bwd_kernel, dim3(ft_cdiv(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dout, x12,
                      x, d12, dx, rows, C);
   return ft_check_launch("highway_gate_bwd");
+}
+
+int ft_highway_pack(const float* w1, const float* w2, float* w12i, int C, void* stream) {
+  FT_REQUIRE(C > 0 && C % 32 == 0, "highway_pack: the fused highway needs C %% 32 == 0 (C = %d)", C);
+  hipLaunchKernelGGL(ft_highway_pack_kernel, dim3(ft_cdiv(2L * C * C, 256)), dim3(256), 0, (hipStream_t)stream, w1, w2,
+                     w12i, C);
+  return ft_check_launch("highway_pack");
 }
 
 int ft_maxpool2_fwd(const float* x, float* out, int B, int T, int C, void* stream) {

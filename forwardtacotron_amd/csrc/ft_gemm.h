@@ -59,7 +59,121 @@ struct FtGemmBatch {
   // task 0's M, N, output and epilogue (conv-bank data gradient: every member adds into the same dx)
   int chain;
   int stat_fused;       // out: 1 if the launched kernel produced the tasks' BatchNorm statistics
+  // Highway epilogues (HighwayNetwork, common_layers.py:35-40) of a single-task or chained launch with identity output
+  // rows -- the north-star's "Highway fused": the gate never runs as a kernel of its own.
+  //  hw_mode 1 (forward): B is the 32-row interleave of W1 / W2 (ft_highway_pack), N = 2 * hw_C; output column n is unit
+  //    (n / 64) * 32 + n % 32 of y1 (n % 64 < 32) or of y2, so a wave's two 32-column tiles -- or, in the 64-column
+  //    tiling, the two waves of a tile row -- hold y1 and y2 of the same units.  The epilogue writes
+  //    out = g * relu(y1) + (1 - g) * x, g = sigmoid(y2), to C (ldc) and, if hw_x12 is set, the pre-activations
+  //    [M, 2 * hw_C] = y1 | y2 (what the backward needs).  Biases hw_b1 / hw_b2 (task bias unused).
+  //  hw_mode 2 (backward): the product (+ C when accumulate is set) is d(out) of the layer BELOW the one whose data
+  //    gradient is being formed; the epilogue turns it into that layer's gate gradients at once:
+  //    hw_d12 [M, 2 * hw_C] = d * g * (y1 > 0) | d * (relu(y1) - x) * g * (1 - g),  C = d * (1 - g)  (y1 | y2 = hw_x12).
+  int hw_mode, hw_C;
+  const float* hw_x;
+  const float* hw_b1;
+  const float* hw_b2;
+  float* hw_x12;
+  float* hw_d12;
 };
+
+// The highway epilogues (see FtGemmBatch) for an accumulator tile in the 32x32 MFMA layout shared by the row kernels:
+// wave (wm, wn) of 2 x 2, lane (half, l31) holds column l31 and rows (e & 3) + 8 * (e >> 2) + 4 * half of each tile.
+// lds: >= 2 * 32 * 33 floats of idle LDS (TN == 1 only), safe to overwrite when this is called.  Every thread of the
+// workgroup must call it (TN == 1 synchronises).
+template <int TM, int TN>
+__device__ __forceinline__ void ft_highway_epilogue(const FtGemmBatch& bt, const FtGemmTask& T, float* TC,
+                                                    f32x16 (&acc)[TM][TN], float* lds, int m0, int n0, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int C = bt.hw_C, tM = T.M;
+  const long ldc = T.ldc;
+  const float* hx = bt.hw_x;
+  if (bt.hw_mode == 1) {
+    float* x12 = bt.hw_x12;
+    if constexpr (TN == 2) {
+      const int unit = ((n0 + wn * 64) >> 6) * 32 + l31;              // both 32-column tiles of this wave: the same units
+      const bool uok = unit < C;
+      const float b1 = uok ? bt.hw_b1[unit] : 0.f, b2 = uok ? bt.hw_b2[unit] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (row >= tM || !uok) continue;
+          const float y1 = acc[i][0][e] + b1, y2 = acc[i][1][e] + b2;
+          const float g = ft_sigmoid(y2);
+          if (x12) {
+            x12[(long)row * 2 * C + unit] = y1;
+            x12[(long)row * 2 * C + C + unit] = y2;
+          }
+          TC[(long)row * ldc + unit] = g * fmaxf(y1, 0.f) + (1.f - g) * hx[(long)row * C + unit];
+        }
+    } else {
+      static_assert(TN == 1 || TN == 2, "highway epilogue: 32- or 64-column waves");
+      // 64-column tiles: wave wn = 0 holds y1, wave wn = 1 y2 of the same 32 units -> the gate travels through LDS
+      const int unit = (n0 >> 6) * 32 + l31;
+      const bool uok = unit < C;
+      float* gl = lds + wm * (32 * TM) * 33;
+      if (wn == 1) {
+        const float b2 = uok ? bt.hw_b2[unit] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int rl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int row = m0 + wm * 32 * TM + rl;
+            const float y2 = acc[i][0][e] + b2;
+            gl[rl * 33 + l31] = ft_sigmoid(y2);
+            if (x12 && row < tM && uok) x12[(long)row * 2 * C + C + unit] = y2;
+          }
+      }
+      __syncthreads();
+      if (wn == 0) {
+        const float b1 = uok ? bt.hw_b1[unit] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int rl = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int row = m0 + wm * 32 * TM + rl;
+            if (row >= tM || !uok) continue;
+            const float y1 = acc[i][0][e] + b1;
+            const float g = gl[rl * 33 + l31];
+            if (x12) x12[(long)row * 2 * C + unit] = y1;
+            TC[(long)row * ldc + unit] = g * fmaxf(y1, 0.f) + (1.f - g) * hx[(long)row * C + unit];
+          }
+      }
+    }
+    return;
+  }
+  // mode 2
+  const float* x12 = bt.hw_x12;
+  float* d12 = bt.hw_d12;
+  const bool eacc = T.accumulate != 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + l31;
+      if (col >= T.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row >= tM) continue;
+        float* cp = TC + (long)row * ldc + col;
+        float dv = acc[i][j][e];
+        if (eacc) dv += *cp;
+        const float y1 = x12[(long)row * 2 * C + col], y2 = x12[(long)row * 2 * C + C + col];
+        const float g = ft_sigmoid(y2);
+        d12[(long)row * 2 * C + col] = y1 > 0.f ? dv * g : 0.f;
+        d12[(long)row * 2 * C + C + col] = dv * (fmaxf(y1, 0.f) - hx[(long)row * C + col]) * g * (1.f - g);
+        *cp = dv * (1.f - g);
+      }
+    }
+}
+
 
 // out_tap[m][n] = sum_r Amap(A)[r][m] * Bmap_tap(B)[r][n],  r over R logical rows   ("TN", split over rows)
 // result written to dst[m*ldm + n*ldn + tap*ldj]  (deterministic slab + reduce)

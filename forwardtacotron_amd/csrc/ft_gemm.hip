@@ -280,6 +280,10 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
     __syncthreads();
   }
 
+  if (batch.hw_mode) {                        // highway gate / gate gradient in the epilogue (ft_gemm.h)
+    ft_highway_epilogue<TM, TN>(batch, T, TC, acc, smem, m0, n0, tid);
+    return;
+  }
   // epilogue: lane holds column l31, rows (e&3) + 8*(e>>2) + 4*half of each 32x32 tile
   const float* ebias = T.bias;
   const float* escale = T.scale;

@@ -309,6 +309,10 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
     }
   }
 
+  if (batch.hw_mode) {                                  // highway gate / gate gradient in the epilogue (ft_gemm.h)
+    ft_highway_epilogue<TM, TN>(batch, T, TC, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+    return;
+  }
   rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, blockIdx.x);
 }
 
@@ -649,6 +653,10 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     mfma_on(fa, fb);
   }
   __syncthreads();                                   // the epilogue's statistics scratch aliases the tiles
+  if (batch.hw_mode) {                                // highway gate / gate gradient in the epilogue (ft_gemm.h)
+    ft_highway_epilogue<TM, TN>(batch, T, TC, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
+    return;
+  }
   rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, bx);
 }
 

@@ -221,9 +221,11 @@ class PackCache:
     mats: 2-D weights; convs: 3-D Conv1d weights used on their own; banks: lists of Conv1d weights (k = 1..K, equal
     [C,Cin]) whose packs must sit back to back (CBHG conv bank)."""
 
-    def __init__(self, mats, convs, banks, device):
+    def __init__(self, mats, convs, banks, device, highways=()):
+        """highways: (W1, W2) pairs of HighwayNetworks whose width is a multiple of 32 -> their 32-row interleave
+        (ft_highway_pack layout), the B operand of the fused highway forward"""
         import struct
-        self.wp, self.wpt, self.t2d, self.bank = {}, {}, {}, {}
+        self.wp, self.wpt, self.t2d, self.bank, self.hw = {}, {}, {}, {}, {}
         self._keep = []
         descs = []
         tiles = 0
@@ -259,6 +261,16 @@ class PackCache:
                 add(w, wp_all[off:off + k * C * Cin], wpt_all[off:off + k * C * Cin], C, Cin, k)
                 off += k * C * Cin
             self.bank[tuple(w.data_ptr() for w in ws)] = (wp_all, wpt_all)
+        for w1, w2 in highways:
+            _chk(w1, 'w1'); _chk(w2, 'w2')
+            C = w1.shape[0]
+            if w1.shape != (C, C) or w2.shape != (C, C) or C % 32:
+                continue
+            pack = torch.empty(2 * C, C, device=device, dtype=w1.dtype)
+            self.hw[(w1.data_ptr(), w2.data_ptr())] = pack
+            for j in range(C // 32):        # plain [32, C] row-block copies (dst only, one tap)
+                add(w1[32 * j:32 * j + 32], pack[64 * j:64 * j + 32], None, 32, C, 1)
+                add(w2[32 * j:32 * j + 32], pack[64 * j + 32:64 * j + 64], None, 32, C, 1)
         self.n, self.tiles = len(descs), tiles
         self.descs = torch.frombuffer(bytearray(b''.join(descs)), dtype=torch.uint8).to(device) if descs else None
         # bf16 pieces ("planes", include/fwdtaco_hip.h: ft_planes_*) of every matrix a GEMM may take as its B operand:
@@ -716,6 +728,45 @@ def highway_gate_bwd(dout, x12, x):
     dx = torch.empty_like(x)
     _lib.call('ft_highway_gate_bwd', _p(dout), _p(x12), _p(x), _p(d12), _p(dx), x.numel() // C, C, _stream())
     return d12, dx
+
+
+def highway_pack(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """the 32-row interleave [2C, C] of W1 / W2 (include/fwdtaco_hip.h: ft_highway_pack); from the step's PackCache if it
+    holds this pair"""
+    if pack_cache is not None:
+        hit = pack_cache.hw.get((w1.data_ptr(), w2.data_ptr()))
+        if hit is not None:
+            return hit
+    _chk(w1, 'w1'); _chk(w2, 'w2')
+    C = w1.shape[0]
+    out = torch.empty(2 * C, C, device=w1.device, dtype=w1.dtype)
+    _lib.call('ft_highway_pack', _p(w1), _p(w2), _p(out), C, _stream())
+    return out
+
+
+def highway_fwd(x: torch.Tensor, w12i: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor, save: bool):
+    """HighwayNetwork forward with the gate in the GEMM epilogue -> (out [.., C], x12 [.., 2C] or None)"""
+    _chk(x, 'x'); _chk(w12i, 'w12i')
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty_like(x)
+    x12 = torch.empty(*x.shape[:-1], 2 * C, device=x.device, dtype=x.dtype) if save else None
+    _lib.call('ft_highway_fwd', _p(x), _p(w12i), _p(b1), _p(b2), _p(out), _p(x12), rows, C, _stream())
+    return out, x12
+
+
+def highway_bwd_data(d12: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor, dx: torch.Tensor,
+                     below: Optional[tuple] = None) -> Optional[torch.Tensor]:
+    """dx += d12[:, :C] W1 + d12[:, C:] W2 (in place; dx holds the direct-path term).  below = (x12, x) of the highway
+    layer underneath: dx then becomes THAT layer's direct-path term and its gate gradients d12 [.., 2C] are returned."""
+    C = dx.shape[-1]
+    rows = dx.numel() // C
+    flag = 1 if NT_GRADS else 0
+    wa, wb = (transpose2d(w1), transpose2d(w2)) if flag else (w1, w2)
+    d12b = torch.empty_like(d12) if below is not None else None
+    _lib.call('ft_highway_bwd_data', _p(d12), _p(wa), _p(wb), flag, _p(dx), rows, C,
+              _p(below[0]) if below else None, _p(below[1]) if below else None, _p(d12b), _stream())
+    return d12b
 
 
 def maxpool2_fwd(x: torch.Tensor) -> torch.Tensor:

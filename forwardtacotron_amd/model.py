@@ -220,8 +220,7 @@ class CBHG(nn.Module):
         y = _dropout(y, self.dropout, self.training)
         y = self.conv_project2(y, residual=x)
         y = ops.LinearFn.apply(y, self.pre_highway.weight, None)
-        for h in self.highways:
-            y = h(y)
+        y = ops.highway_stack(y, list(self.highways))     # gates inside the GEMM epilogues (width % 32 == 0)
         return self.rnn(y, time_major_out=time_major_out)
 
 

@@ -479,6 +479,69 @@ class HighwayFn(Function):
         return dx, dw1, db1, dw2, db2
 
 
+class HighwayStackFn(Function):
+    """A CBHG's stack of HighwayNetworks (common_layers.py:35-40, 86-88, 117-118) with every gate inside a GEMM: the
+    forward gate is the epilogue of the layer's one W1 | W2 product (weights interleaved so that a lane holds both
+    pre-activations of a unit), and the gate gradient of layer i - 1 is the epilogue of layer i's data-gradient product
+    (whose result IS d(out) of layer i - 1).  Only the top layer's gate gradient still runs as a kernel (its d(out)
+    comes from the GRU above).  Needs width % 32 == 0; other widths take HighwayFn per layer.
+    args: x, then (W1, b1, W2, b2) per layer."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        x = _c(x)
+        L = len(params) // 4
+        train = any(ctx.needs_input_grad)
+        xs, x12s = [x], []
+        for i in range(L):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            out, x12 = H.highway_fwd(xs[-1], H.highway_pack(w1, w2), b1, b2, save=train)
+            xs.append(out)
+            x12s.append(x12)
+        if train:
+            ctx.save_for_backward(*xs[:L], *x12s, *params)
+        ctx.L = L
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = ctx.L
+        saved = ctx.saved_tensors
+        xs, x12s, params = saved[:L], saved[L:2 * L], saved[2 * L:]
+        C = xs[0].shape[-1]
+        rows = xs[0].numel() // C
+        d12, dx = H.highway_gate_bwd(_c(dout), x12s[L - 1], xs[L - 1])
+        grads = [None] * (4 * L)
+        for i in range(L - 1, -1, -1):
+            w1, b1, w2, b2 = params[4 * i:4 * i + 4]
+            x = xs[i]
+            d12_below = H.highway_bwd_data(d12, w1, w2, dx, below=(x12s[i - 1], xs[i - 1]) if i > 0 else None)
+            p = d12.data_ptr()
+            grads[4 * i] = _emit(w1, lambda out, p=p, x=x: H.linear_bwd_weight_raw(p, 2 * C, x.data_ptr(), C, out, rows, C, C),
+                                 (d12, x))
+            grads[4 * i + 2] = _emit(w2, lambda out, p=p, x=x: H.linear_bwd_weight_raw(p + C * _F4, 2 * C, x.data_ptr(), C, out,
+                                                                                    rows, C, C), (d12, x))
+            grads[4 * i + 1] = _emit(b1, lambda out, p=p: H.colsum_raw(p, 2 * C, out, rows, C), (d12,), heavy='light')
+            grads[4 * i + 3] = _emit(b2, lambda out, p=p: H.colsum_raw(p + C * _F4, 2 * C, out, rows, C), (d12,),
+                                     heavy='light')
+            d12 = d12_below
+        return (dx, *grads)
+
+
+def highway_stack(x, highways):
+    """x through the HighwayNetwork modules `highways` (each has .W1 / .W2 Linear containers)"""
+    if not highways:
+        return x
+    if x.shape[-1] % 32 == 0 and os.environ.get('FT_HIGHWAY_FUSED', '1') == '1':
+        flat = []
+        for h in highways:
+            flat += [h.W1.weight, h.W1.bias, h.W2.weight, h.W2.bias]
+        return HighwayStackFn.apply(x, *flat)
+    for h in highways:
+        x = HighwayFn.apply(x, h.W1.weight, h.W1.bias, h.W2.weight, h.W2.bias)
+    return x
+
+
 # ---------------------------------------------------------------------------------------------------
 def _rnn_param_grads(dxp, dhp, x, hid, G, Hh, params, need_dx, late_last=False):
     """Shared tail of the GRU/LSTM backward: weight / bias / input gradients from the per-step

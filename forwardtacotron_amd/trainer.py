@@ -175,9 +175,11 @@ class TrainStep:
                     in_bank.update(id(w) for w in ws)
             emb = {id(p) for m in self.model.modules() if isinstance(m, torch.nn.Embedding) for p in m.parameters()}
             ps = [p for p in self.flat.params if p.dtype == torch.float32 and id(p) not in emb]
+            highways = [(m.W1.weight, m.W2.weight) for m in self.model.modules()
+                        if hasattr(m, 'W1') and hasattr(m, 'W2') and isinstance(m.W1, torch.nn.Linear)]
             self.packs = H.PackCache(mats=[p for p in ps if p.dim() == 2],
                                      convs=[p for p in ps if p.dim() == 3 and id(p) not in in_bank],
-                                     banks=banks, device=self.flat.flat.device)
+                                     banks=banks, device=self.flat.flat.device, highways=highways)
             self._packs_base = self.flat.flat.data_ptr()
         return self.packs
 

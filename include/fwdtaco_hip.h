@@ -293,6 +293,21 @@ int ft_highway_gate_fwd(const float* x12, const float* x, float* out, long rows,
 int ft_highway_gate_bwd(const float* dout, const float* x12, const float* x, float* d12, float* dx, long rows, int C,
                         void* stream);
 
+/* The same layer with the gate INSIDE the GEMMs (C % 32 == 0; the two calls above stay for other widths).
+ * ft_highway_pack: w12i [2C, C] = the 32-row interleave of W1 and W2 (row n: unit (n/64)*32 + n%32 of W1 if n%64 < 32, else
+ *   of W2), so that one accumulator lane pair holds W1 x and W2 x of the same unit.
+ * ft_highway_fwd: out [rows, C] = g * relu(y1) + (1 - g) * x with y1 | y2 = x W1^T + b1 | x W2^T + b2, g = sigmoid(y2), from
+ *   the epilogue of ONE product x * w12i^T; x12 (may be NULL) receives y1 | y2 as [rows, 2C] for the backward.
+ * ft_highway_bwd_data: dx [rows, C] += d12[:, :C] W1 + d12[:, C:] W2 (dx holds the direct-path term; w1 / w2 are W^T
+ *   [C, C] if w_transposed).  With below_* set, dx is d(out) of the highway layer BELOW and the epilogue turns it into that
+ *   layer's ft_highway_gate_bwd outputs at once: below_d12 [rows, 2C] and dx = direct-path term of the layer below
+ *   (below_x12 / below_x = that layer's saved pre-activations and input). */
+int ft_highway_pack(const float* w1, const float* w2, float* w12i, int C, void* stream);
+int ft_highway_fwd(const float* x, const float* w12i, const float* b1, const float* b2, float* out, float* x12, int rows,
+                   int C, void* stream);
+int ft_highway_bwd_data(const float* d12, const float* w1, const float* w2, int w_transposed, float* dx, int rows, int C,
+                        const float* below_x12, const float* below_x, float* below_d12, void* stream);
+
 /* ---- MaxPool1d(kernel 2, stride 1, padding 1)[:T] (common_layers.py:78,105): out[t]=max(x[t-1],x[t]) ---- */
 int ft_maxpool2_fwd(const float* x, float* out, int B, int T, int C, void* stream);
 int ft_maxpool2_bwd(const float* dout, const float* x, float* dx, int B, int T, int C, void* stream);

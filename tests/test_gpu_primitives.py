@@ -554,3 +554,66 @@ def test_weight_gradient_pipelined_kernel(H, form):
                 ref = dyk.reshape(-1, C).t() @ xs.reshape(-1, Cin)
                 assert rel_err(dws[i][:, :, j], ref) < 3e-6, (kk, j)
         assert _tn_pipelined() - n0 == 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# HighwayNetwork with the gate inside the GEMM epilogues (common_layers.py:35-40; ops.HighwayStackFn)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rows,C,layers', [(300, 64, 3), (4096, 256, 4), (25000, 128, 2), (77, 32, 1), (26912, 256, 2)])
+def test_highway_stack_gates_in_the_gemm_epilogues(H, rows, C, layers, monkeypatch):
+    """ops.highway_stack (forward gate = epilogue of the interleaved W1 | W2 product, gate gradient of layer i - 1 =
+    epilogue of layer i's data-gradient product) against float64 math and against the unfused per-layer form: rows /
+    widths that take the 64-column tiling (gate through LDS between the two waves of a tile row) and the 128-column
+    split kernel (both pre-activations in one lane), odd row counts, 1 .. 4 layers."""
+    from forwardtacotron_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+
+    class Hw:                                    # parameter containers like model.HighwayNetwork
+        def __init__(self):
+            self.W1 = torch.nn.Linear(C, C)
+            self.W2 = torch.nn.Linear(C, C)
+            for p in (self.W1.weight, self.W2.weight):
+                p.data = torch.randn(C, C, generator=g) * (1.0 / C ** 0.5)
+            for p in (self.W1.bias, self.W2.bias):
+                p.data = torch.randn(C, generator=g) * 0.3
+            self.W1.cuda(); self.W2.cuda()
+
+    hs = [Hw() for _ in range(layers)]
+    x = torch.randn(rows, C, generator=g)
+    w = torch.randn(rows, C, generator=g)
+    res = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('FT_HIGHWAY_FUSED', fused)
+        for h in hs:
+            for p in (h.W1.weight, h.W1.bias, h.W2.weight, h.W2.bias):
+                p.grad = None
+        xg = x.cuda().requires_grad_(True)
+        y = ops.highway_stack(xg, hs)
+        (y * w.cuda()).sum().backward()
+        res[fused] = (y.detach().cpu(), xg.grad.cpu(),
+                      [p.grad.cpu() for h in hs for p in (h.W1.weight, h.W1.bias, h.W2.weight, h.W2.bias)])
+    xo = x.double().requires_grad_(True)
+    Po = [[p.detach().cpu().double().requires_grad_(True) for p in (h.W1.weight, h.W1.bias, h.W2.weight, h.W2.bias)]
+          for h in hs]
+    yo = xo
+    for w1, b1, w2, b2 in Po:
+        gt = torch.sigmoid(yo @ w2.t() + b2)
+        yo = gt * torch.relu(yo @ w1.t() + b1) + (1. - gt) * yo
+    (yo * w.double()).sum().backward()
+    # against float64: a ReLU pre-activation within fp32 rounding of zero flips its 0 / 1 derivative (a handful of the
+    # rows x C x layers decisions), and one flip changes a whole row of dx -- 99.5 % of the elements must agree
+    def close(got, want, tol):
+        err = ((got.double() - want.double()).abs() / max(1.0, float(want.abs().max()))).flatten()
+        return float(err.kthvalue(max(1, int(err.numel() * 0.995)))[0]) < tol
+    for tag in ('1', '0'):
+        y, dx, gr = res[tag]
+        assert maxdiff(y, yo.detach()) < 2e-5 * max(1.0, float(yo.abs().max())), tag
+        assert close(dx, xo.grad, 2e-5), tag
+        for got, want in zip(gr, [p.grad for ps in Po for p in ps]):
+            assert close(got, want, 1e-4), tag
+    # against the per-layer form (pinned by the reference's goldens, test_maxpool_highway_golden / the model tests): the
+    # same products in the same order and the same gate arithmetic
+    assert maxdiff(res['1'][0], res['0'][0]) <= 1e-6 * max(1.0, float(yo.abs().max()))
+    assert maxdiff(res['1'][1], res['0'][1]) <= 1e-6 * max(1.0, float(xo.grad.abs().max()))
+    for a, b in zip(res['1'][2], res['0'][2]):
+        assert maxdiff(a, b) <= 1e-6 * max(1.0, float(b.abs().max()))
