@@ -9,6 +9,7 @@ Activations are batch-major channels-last [B,T,d] (the reference's [T,B,d] is on
 import copy
 import functools
 import math
+import os
 from pathlib import Path
 from typing import Any, Callable, Dict, Optional, Union
 
@@ -66,6 +67,16 @@ class MHAFn(Function):
         hd = d // nh
         scale = 1.0 / math.sqrt(hd)
         qkv = H.linear_fwd(x, in_w, in_b)                                   # [B,T,3d]
+        # bf16 mode: ONE flash-style kernel between the two projections -- no [B,h,T,T] tensor in memory, the backward
+        # recomputes the probabilities (csrc/ft_attn.hip); FT_ATTN_FUSED=0: the five-launch form below in bf16 too
+        if H.gemm_precision_mode() == 'bf16' and hd in (64, 128) and os.environ.get('FT_ATTN_FUSED', '1') == '1':
+            att, lse2 = H.attn_fwd(qkv, key_pad, nh, scale, p_drop, seed)
+            out = H.linear_fwd(att, out_w, out_b)
+            ctx.save_for_backward(x, qkv, lse2, att, key_pad, in_w, in_b, out_w, out_b, lse2)
+            ctx.meta = (nh, hd, scale, float(p_drop), int(seed))
+            ctx.fused = True
+            return out
+        ctx.fused = False
         # the [T,T] score / probability matrices are kept with their row stride rounded up to 4 floats (pad columns
         # are zeros): T = 841 frames would otherwise push four of the six attention GEMMs off the 16-B-load paths
         Tp = (T + 3) // 4 * 4
@@ -97,6 +108,13 @@ class MHAFn(Function):
         g_ow = _emit(out_w, lambda o: H.linear_bwd_weight_raw(dout.data_ptr(), d, att.data_ptr(), d, o, rows, d, d),
                      (dout, att))
         g_ob = _emit(out_b, lambda o: H.colsum_raw(dout.data_ptr(), d, o, rows, d), heavy=False)
+        if ctx.fused:           # (P is the saved lse2 here)
+            dqkv = H.attn_bwd(qkv, att, datt, key_pad, P, nh, scale, p_drop, seed)
+            g0 = dqkv.data_ptr()
+            dx = H.linear_bwd_data(dqkv, in_w) if ctx.needs_input_grad[0] else None
+            g_iw = _emit(in_w, lambda o: H.linear_bwd_weight_raw(g0, 3 * d, x.data_ptr(), d, o, rows, d, 3 * d), (dqkv, x))
+            g_ib = _emit(in_b, lambda o: H.colsum_raw(g0, 3 * d, o, rows, 3 * d), heavy=False)
+            return dx, None, g_iw, g_ib, g_ow, g_ob, None, None, None
         q0 = qkv.data_ptr()
         dqkv = torch.empty_like(qkv)
         g0 = dqkv.data_ptr()

@@ -66,6 +66,12 @@ def _ptr_array(ts: Sequence[Optional[torch.Tensor]]):
 # matmul precision (process-wide switch of the library, include/fwdtaco_hip.h: ft_set_gemm_precision)
 # ---------------------------------------------------------------------------------------------------
 _PRECISIONS = {'fp32': 0, 'bf16': 1}
+_precision_now = 'fp32'
+
+
+def gemm_precision_mode() -> str:
+    """the mode set_gemm_precision last installed"""
+    return _precision_now
 
 
 def set_gemm_precision(mode: str) -> str:
@@ -73,7 +79,9 @@ def set_gemm_precision(mode: str) -> str:
     accumulation and outputs); returns the previous mode"""
     if mode not in _PRECISIONS:
         raise _lib.FtError(f"gemm precision must be 'fp32' or 'bf16', got {mode!r}")
+    global _precision_now
     old = _lib.lib().ft_set_gemm_precision(_PRECISIONS[mode])
+    _precision_now = mode
     return 'bf16' if old else 'fp32'
 
 
@@ -84,6 +92,32 @@ def gemm_precision(mode: str):
         yield
     finally:
         set_gemm_precision(old)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused attention (bf16 mode)
+# ---------------------------------------------------------------------------------------------------
+def attn_fwd(qkv: torch.Tensor, key_pad: Optional[torch.Tensor], nheads: int, scale: float, p_drop: float, seed: int):
+    """qkv [B,T,3d] -> (att [B,T,d], lse2 [B,nheads,T]); include/fwdtaco_hip.h: ft_attn_fwd"""
+    _chk(qkv, 'qkv')
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    att = torch.empty(B, T, d, device=qkv.device, dtype=qkv.dtype)
+    lse2 = torch.empty(B, nheads, T, device=qkv.device, dtype=qkv.dtype)
+    _lib.call('ft_attn_fwd', _p(qkv), _p(key_pad), _p(att), _p(lse2), B, T, nheads, d // nheads, float(scale),
+              float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+    return att, lse2
+
+
+def attn_bwd(qkv, att, datt, key_pad, lse2, nheads: int, scale: float, p_drop: float, seed: int) -> torch.Tensor:
+    _chk(datt, 'datt')
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    dqkv = torch.empty_like(qkv)
+    ws = workspace(_lib.query('ft_attn_workspace', B, T, nheads), qkv.device)
+    _lib.call('ft_attn_bwd', _p(qkv), _p(att), _p(datt), _p(key_pad), _p(lse2), _p(dqkv), B, T, nheads, d // nheads,
+              float(scale), float(p_drop), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(ws), ws.numel(), _stream())
+    return dqkv
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -434,6 +434,23 @@ int ft_guarded_restore(void* dst, const void* snapshot, long nwords, const float
 int ft_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                  float beta2, float eps, long step, const float* coef, void* stream);
 
+/* ---- fused self-attention, bf16 matmul mode (nn.MultiheadAttention inside FFTBlock, common_layers.py:172-174) ---- */
+/* qkv [B,T,3d] = the in-projection's output rows (q | k | v, d = nheads*hd, head h at columns h*hd of each third), fp32;
+ * key_pad [B,T] bytes (non-zero = padded key) or NULL.  ft_attn_fwd: att [B,T,d] = concat_h softmax(scale q_h k_h^T +
+ * mask) v_h with attention dropout p_drop (the counter-based mask of ft_softmax_fwd: element index = flat index into
+ * [B,nheads,T,T], same seed -> same mask), and lse2 [B,nheads,T] = log2-domain log-sum-exp per query row for the
+ * backward.  One flash-style launch: the [B,nheads,T,T] scores never reach memory.  Operands are rounded to bf16 while
+ * staged (bf16 MFMA, fp32 statistics / accumulation / outputs): this IS the bf16 mode, there is no fp32-exact variant (the
+ * fp32 mode keeps ft_bgemm_* + ft_softmax_*).  hd = 64 or 128.
+ * ft_attn_bwd: dqkv [B,T,3d] (every element written) from datt = d(att); recomputes the probabilities from qkv and lse2
+ * (three launches: row sums of datt*att, dQ, dK+dV; no atomics, bitwise reproducible).  workspace: ft_attn_workspace. */
+size_t ft_attn_workspace(int B, int T, int nheads);
+int ft_attn_fwd(const float* qkv, const unsigned char* key_pad, float* att, float* lse2, int B, int T, int nheads, int hd,
+                float scale, float p_drop, uint64_t seed, void* stream);
+int ft_attn_bwd(const float* qkv, const float* att, const float* datt, const unsigned char* key_pad, const float* lse2,
+                float* dqkv, int B, int T, int nheads, int hd, float scale, float p_drop, uint64_t seed, void* workspace,
+                size_t workspace_bytes, void* stream);
+
 /* ---- mel inversion + Griffin-Lim (utils/dsp.py:80-94 DSP.griffinlim ; gen_forward.py:109-116) ------------ */
 /* The DFTs are GEMMs on ft_linear_fwd (frames read in place out of the zero-padded signal with ldx = hop); these are
  * the element-wise / gather pieces.  Complex spectra are split [N][2*Fp] = Re | Im, Fp = F rounded up to 4.

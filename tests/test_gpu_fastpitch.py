@@ -452,3 +452,78 @@ def test_fastpitch_bf16_mid_size_vs_fp32_oracle():
                pitch_d_fft=40, energy_d_model=24, energy_n_heads=3, energy_d_fft=32, d_model=64, conv1_kernel=9,
                conv2_kernel=1, prenet_fft=96, prenet_heads=2, postnet_fft=128, postnet_heads=2, n_mels=20)
     _bf16_vs_oracle(cfg, B=4, Tmax=23, n_mels=20, seed=5, tol_mel=8e-2, tol_loss=5e-3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused attention of the bf16 mode (csrc/ft_attn.hip): one flash-style kernel, backward by recomputation
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,T,d,nh,p_drop,ragged', [(2, 70, 128, 2, 0.0, True), (2, 70, 128, 2, 0.1, True),
+                                                    (3, 200, 256, 2, 0.0, True), (2, 333, 256, 2, 0.1, True),
+                                                    (1, 64, 256, 2, 0.0, False), (2, 129, 128, 2, 0.0, True),
+                                                    (2, 841, 256, 2, 0.1, True)])
+def test_fused_attention_vs_float64_on_the_rounded_operands(B, T, d, nh, p_drop, ragged):
+    """ft_attn_fwd / ft_attn_bwd (QK^T -> masked softmax -> dropout -> PV in one kernel; no [B,h,T,T] tensor; backward
+    recomputes from the saved log-sum-exp) against float64 attention (nn.MultiheadAttention's need_weights branch,
+    common_layers.py:172-174, as oracle/fp_oracle.mha writes it out) on the SAME bf16-rounded q / k / v -- what is left is
+    the bf16 rounding of the probabilities and fp32 accumulation: 1e-2 of the result's range.  The attention dropout is
+    the library's counter-based mask (element index = flat index into [B,h,T,T]), reproduced here through ft_dropout on
+    an index-shaped tensor, so the dropped variant is compared exactly too.  Head widths 64 and 128, ragged key padding,
+    T not a multiple of the 64-key block / 128-query workgroup, the benchmark's T = 841."""
+    import math
+    from forwardtacotron_amd import hip as H
+    torch.manual_seed(B * 1000 + T)
+    hd = d // nh
+    qkv = torch.randn(B, T, 3 * d, device='cuda') * 0.7
+    lens = torch.randint(max(1, T // 2), T + 1, (B,))
+    lens[0] = T
+    key_pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8).cuda() if ragged else None
+    scale, seed = 1.0 / math.sqrt(hd), 1234567
+    att, lse2 = H.attn_fwd(qkv, key_pad, nh, scale, p_drop, seed)
+    datt = torch.randn(B, T, d, device='cuda')
+    dqkv = H.attn_bwd(qkv, att, datt, key_pad, lse2, nh, scale, p_drop, seed)
+    again = H.attn_bwd(qkv, att, datt, key_pad, lse2, nh, scale, p_drop, seed)
+    assert torch.equal(dqkv, again)                                     # no atomics: bitwise reproducible
+    q, k, v = [t.bfloat16().double().cpu().reshape(B, T, nh, hd).permute(0, 2, 1, 3).requires_grad_(True)
+               for t in qkv.split(d, dim=-1)]
+    s = (q @ k.transpose(-1, -2)) * scale
+    if key_pad is not None:
+        s = s.masked_fill(key_pad.bool().cpu()[:, None, None, :], float('-inf'))
+    P = torch.softmax(s, dim=-1)
+    if p_drop > 0:
+        keep = (H.dropout(torch.ones(B * nh * T * T, device='cuda'), p_drop, seed) > 0).double().cpu().reshape(B, nh, T, T)
+        assert 0.85 < float(keep.mean()) < 0.95
+        P = P * keep / (1 - p_drop)
+    o = (P @ v).permute(0, 2, 1, 3).reshape(B, T, d)
+    (o * datt.double().cpu()).sum().backward()
+    assert maxdiff(att.cpu(), o.detach()) < 1e-2 * float(o.detach().abs().max())
+    want = [t.grad.permute(0, 2, 1, 3).reshape(B, T, d) for t in (q, k, v)]
+    for got, ref, name in zip(dqkv.cpu().split(d, dim=-1), want, 'qkv'):
+        assert maxdiff(got, ref) < 1e-2 * float(ref.abs().max()), name
+    if key_pad is not None:                                             # a padded key gets no gradient at all
+        pad = key_pad.bool().cpu()
+        assert float(dqkv.cpu()[:, :, d:][pad].abs().max() if pad.any() else 0.0) == 0.0
+
+
+def test_bf16_attention_fused_equals_the_five_launch_form(monkeypatch):
+    """MHAFn in bf16 mode, fused (default) against FT_ATTN_FUSED=0 (QK^T / softmax / PV and the four gradient products
+    as separate launches with the [B,h,T,T] tensors in memory): outputs and every gradient agree to bf16 rounding."""
+    from forwardtacotron_amd import hip as H
+    from forwardtacotron_amd.fastpitch import MHAFn
+    torch.manual_seed(5)
+    B, T, d, nh = 3, 150, 256, 2
+    x = torch.randn(B, T, d)
+    in_w, in_b = torch.randn(3 * d, d) / d ** 0.5, torch.randn(3 * d) * 0.1
+    out_w, out_b = torch.randn(d, d) / d ** 0.5, torch.randn(d) * 0.1
+    lens = torch.tensor([150, 97, 120])
+    key_pad = (torch.arange(T)[None, :] >= lens[:, None]).to(torch.uint8).cuda()
+    w = torch.randn(B, T, d).cuda()
+    res = {}
+    with H.gemm_precision('bf16'):
+        for fused in ('1', '0'):
+            monkeypatch.setenv('FT_ATTN_FUSED', fused)
+            ps = [t.clone().cuda().requires_grad_(True) for t in (x, in_w, in_b, out_w, out_b)]
+            y = MHAFn.apply(ps[0], key_pad, ps[1], ps[2], ps[3], ps[4], nh, 0.1, 99)
+            (y * w).sum().backward()
+            res[fused] = [y.detach().cpu()] + [p.grad.cpu() for p in ps]
+    for a, b_ in zip(res['1'], res['0']):
+        assert maxdiff(a, b_) < 2e-2 * float(b_.abs().max())
