@@ -55,66 +55,55 @@ def precision_scoped(fn):
     return wrapped
 
 
-class MHAFn(Function):
-    """nn.MultiheadAttention(d, nheads, dropout)(x, x, x, key_padding_mask=key_pad)[0]  (common_layers.py:172-174)
-    on batch-major x [B,T,d]; key_pad uint8 [B,T] (1 = padded key) or None."""
+def mha_fwd(x, key_pad, in_w, in_b, out_w, out_b, nheads, p_drop, seed):
+    """nn.MultiheadAttention(d, nheads, dropout)(x, x, x, key_padding_mask=key_pad)[0]  (common_layers.py:172-174) on
+    batch-major x [B,T,d]; key_pad uint8 [B,T] (1 = padded key) or None.  -> (out, tape for mha_bwd)"""
+    B, T, d = x.shape
+    nh = int(nheads)
+    hd = d // nh
+    scale = 1.0 / math.sqrt(hd)
+    qkv = H.linear_fwd(x, in_w, in_b)                                   # [B,T,3d]
+    tape = dict(x=x, qkv=qkv, key_pad=key_pad, nh=nh, hd=hd, scale=scale, p=float(p_drop), seed=int(seed))
+    # bf16 mode: ONE flash-style kernel between the two projections -- no [B,h,T,T] tensor in memory, the backward
+    # recomputes the probabilities (csrc/ft_attn.hip); FT_ATTN_FUSED=0: the five-launch form below in bf16 too
+    if H.gemm_precision_mode() == 'bf16' and hd in (64, 128) and os.environ.get('FT_ATTN_FUSED', '1') == '1':
+        att, lse2 = H.attn_fwd(qkv, key_pad, nh, scale, p_drop, seed)
+        tape.update(fused=True, att=att, lse2=lse2)
+        return H.linear_fwd(att, out_w, out_b), tape
+    # the [T,T] score / probability matrices are kept with their row stride rounded up to 4 floats (pad columns
+    # are zeros): T = 841 frames would otherwise push four of the six attention GEMMs off the 16-B-load paths
+    Tp = (T + 3) // 4 * 4
+    P = torch.empty(B, nh, T, Tp, device=x.device, dtype=x.dtype)
+    q0 = qkv.data_ptr()
+    _bgemm('nt', q0, 3 * d, T * 3 * d, hd, q0 + d * _F4, 3 * d, T * 3 * d, hd, P.data_ptr(), Tp, nh * T * Tp, T * Tp,
+           T, T, hd, B, nh, x.device)
+    # softmax and nn.MultiheadAttention's attention dropout in one pass; both P and dropout(P) are kept for backward
+    Pd = torch.empty_like(P) if p_drop > 0 else P
+    _lib.call('ft_softmax_fwd', P.data_ptr(), _p(key_pad), B, nh, T, T, Tp, scale,
+              Pd.data_ptr() if p_drop > 0 else None, float(p_drop), int(seed), H._stream())
+    att = torch.empty(B, T, d, device=x.device, dtype=x.dtype)
+    _bgemm('nn', Pd.data_ptr(), Tp, nh * T * Tp, T * Tp, q0 + 2 * d * _F4, 3 * d, T * 3 * d, hd, att.data_ptr(), d,
+           T * d, hd, T, hd, T, B, nh, x.device, padded=True)
+    tape.update(fused=False, att=att, P=P, Pd=Pd)
+    return H.linear_fwd(att, out_w, out_b), tape
 
-    @staticmethod
-    def forward(ctx, x, key_pad, in_w, in_b, out_w, out_b, nheads, p_drop, seed):
-        x = _c(x)
-        B, T, d = x.shape
-        nh = int(nheads)
-        hd = d // nh
-        scale = 1.0 / math.sqrt(hd)
-        qkv = H.linear_fwd(x, in_w, in_b)                                   # [B,T,3d]
-        # bf16 mode: ONE flash-style kernel between the two projections -- no [B,h,T,T] tensor in memory, the backward
-        # recomputes the probabilities (csrc/ft_attn.hip); FT_ATTN_FUSED=0: the five-launch form below in bf16 too
-        if H.gemm_precision_mode() == 'bf16' and hd in (64, 128) and os.environ.get('FT_ATTN_FUSED', '1') == '1':
-            att, lse2 = H.attn_fwd(qkv, key_pad, nh, scale, p_drop, seed)
-            out = H.linear_fwd(att, out_w, out_b)
-            ctx.save_for_backward(x, qkv, lse2, att, key_pad, in_w, in_b, out_w, out_b, lse2)
-            ctx.meta = (nh, hd, scale, float(p_drop), int(seed))
-            ctx.fused = True
-            return out
-        ctx.fused = False
-        # the [T,T] score / probability matrices are kept with their row stride rounded up to 4 floats (pad columns
-        # are zeros): T = 841 frames would otherwise push four of the six attention GEMMs off the 16-B-load paths
-        Tp = (T + 3) // 4 * 4
-        P = torch.empty(B, nh, T, Tp, device=x.device, dtype=x.dtype)
-        q0 = qkv.data_ptr()
-        _bgemm('nt', q0, 3 * d, T * 3 * d, hd, q0 + d * _F4, 3 * d, T * 3 * d, hd, P.data_ptr(), Tp, nh * T * Tp, T * Tp,
-               T, T, hd, B, nh, x.device)
-        # softmax and nn.MultiheadAttention's attention dropout in one pass; both P and dropout(P) are kept for backward
-        Pd = torch.empty_like(P) if p_drop > 0 else P
-        _lib.call('ft_softmax_fwd', P.data_ptr(), _p(key_pad), B, nh, T, T, Tp, scale,
-                  Pd.data_ptr() if p_drop > 0 else None, float(p_drop), int(seed), H._stream())
-        att = torch.empty(B, T, d, device=x.device, dtype=x.dtype)
-        _bgemm('nn', Pd.data_ptr(), Tp, nh * T * Tp, T * Tp, q0 + 2 * d * _F4, 3 * d, T * 3 * d, hd, att.data_ptr(), d,
-               T * d, hd, T, hd, T, B, nh, x.device, padded=True)
-        out = H.linear_fwd(att, out_w, out_b)
-        ctx.save_for_backward(x, qkv, P, att, key_pad, in_w, in_b, out_w, out_b, Pd)
-        ctx.meta = (nh, hd, scale, float(p_drop), int(seed))
-        return out
 
-    @staticmethod
-    def backward(ctx, dout):
-        x, qkv, P, att, key_pad, in_w, in_b, out_w, out_b, Pd = ctx.saved_tensors
-        nh, hd, scale, p_drop, seed = ctx.meta
-        dout = _c(dout)
-        B, T, d = x.shape
-        rows = B * T
-        dev = x.device
-        datt = H.linear_bwd_data(dout, out_w)
-        g_ow = _emit(out_w, lambda o: H.linear_bwd_weight_raw(dout.data_ptr(), d, att.data_ptr(), d, o, rows, d, d),
-                     (dout, att))
-        g_ob = _emit(out_b, lambda o: H.colsum_raw(dout.data_ptr(), d, o, rows, d), heavy=False)
-        if ctx.fused:           # (P is the saved lse2 here)
-            dqkv = H.attn_bwd(qkv, att, datt, key_pad, P, nh, scale, p_drop, seed)
-            g0 = dqkv.data_ptr()
-            dx = H.linear_bwd_data(dqkv, in_w) if ctx.needs_input_grad[0] else None
-            g_iw = _emit(in_w, lambda o: H.linear_bwd_weight_raw(g0, 3 * d, x.data_ptr(), d, o, rows, d, 3 * d), (dqkv, x))
-            g_ib = _emit(in_b, lambda o: H.colsum_raw(g0, 3 * d, o, rows, 3 * d), heavy=False)
-            return dx, None, g_iw, g_ib, g_ow, g_ob, None, None, None
+def mha_bwd(tape, dout, in_w, in_b, out_w, out_b, need_dx=True, dx_into=None):
+    """-> (dx or None, g_in_w, g_in_b, g_out_w, g_out_b); dx_into: an existing gradient of x that dx is ADDED onto"""
+    x, qkv, att, key_pad = tape['x'], tape['qkv'], tape['att'], tape['key_pad']
+    nh, hd, scale, p_drop, seed = tape['nh'], tape['hd'], tape['scale'], tape['p'], tape['seed']
+    B, T, d = x.shape
+    rows = B * T
+    dev = x.device
+    datt = H.linear_bwd_data(dout, out_w)
+    g_ow = _emit(out_w, lambda o: H.linear_bwd_weight_raw(dout.data_ptr(), d, att.data_ptr(), d, o, rows, d, d),
+                 (dout, att))
+    g_ob = _emit(out_b, lambda o: H.colsum_raw(dout.data_ptr(), d, o, rows, d), (dout,), heavy='light')
+    if tape['fused']:
+        dqkv = H.attn_bwd(qkv, att, datt, key_pad, tape['lse2'], nh, scale, p_drop, seed)
+        g0 = dqkv.data_ptr()
+    else:
+        P, Pd = tape['P'], tape['Pd']
         q0 = qkv.data_ptr()
         dqkv = torch.empty_like(qkv)
         g0 = dqkv.data_ptr()
@@ -133,10 +122,90 @@ class MHAFn(Function):
                hd, T, hd, T, B, nh, dev, padded=True)
         _bgemm('tn', dP.data_ptr(), Tp, nh * T * Tp, T * Tp, q0, 3 * d, T * 3 * d, hd, g0 + d * _F4, 3 * d, T * 3 * d,
                hd, T, hd, T, B, nh, dev, padded=True)
-        dx = H.linear_bwd_data(dqkv, in_w) if ctx.needs_input_grad[0] else None
-        g_iw = _emit(in_w, lambda o: H.linear_bwd_weight_raw(g0, 3 * d, x.data_ptr(), d, o, rows, d, 3 * d), (dqkv, x))
-        g_ib = _emit(in_b, lambda o: H.colsum_raw(g0, 3 * d, o, rows, 3 * d), heavy=False)
+    dx = None
+    if need_dx:
+        dx = H.linear_bwd_data(dqkv, in_w, dx=dx_into, accumulate=dx_into is not None)
+    g_iw = _emit(in_w, lambda o: H.linear_bwd_weight_raw(g0, 3 * d, x.data_ptr(), d, o, rows, d, 3 * d), (dqkv, x))
+    g_ib = _emit(in_b, lambda o: H.colsum_raw(g0, 3 * d, o, rows, 3 * d), (dqkv,), heavy='light')
+    return dx, g_iw, g_ib, g_ow, g_ob
+
+
+class MHAFn(Function):
+    """mha_fwd / mha_bwd as one autograd node (the layer-level entry; models run whole transformers through
+    TransformerFn)."""
+
+    @staticmethod
+    def forward(ctx, x, key_pad, in_w, in_b, out_w, out_b, nheads, p_drop, seed):
+        out, ctx.tape = mha_fwd(_c(x), key_pad, in_w, in_b, out_w, out_b, nheads, p_drop, seed)
+        ctx.params = (in_w, in_b, out_w, out_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx, g_iw, g_ib, g_ow, g_ob = mha_bwd(ctx.tape, _c(dout), *ctx.params, need_dx=ctx.needs_input_grad[0])
+        ctx.tape = None
         return dx, None, g_iw, g_ib, g_ow, g_ob, None, None, None
+
+
+def addln_fwd(x, res, gamma, beta, eps, p=0.0, seed=0):
+    """LayerNorm(x + dropout_p(res)) in one pass -> (y, tape); res None: plain LayerNorm"""
+    D = x.shape[-1]
+    rows = x.numel() // D
+    s = torch.empty_like(x) if res is not None else x
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=x.dtype)
+    rstd = torch.empty(rows, device=x.device, dtype=x.dtype)
+    p = float(p) if res is not None else 0.0
+    _lib.call('ft_layernorm_fwd', x.data_ptr(), _p(_c(res) if res is not None else None), gamma.data_ptr(),
+              beta.data_ptr(), s.data_ptr() if res is not None else None, y.data_ptr(), mean.data_ptr(),
+              rstd.data_ptr(), rows, D, float(eps), p, int(seed), H._stream())
+    return y, dict(s=s, mean=mean, rstd=rstd, has_res=res is not None, p=p, seed=int(seed))
+
+
+def addln_bwd(tape, dy, gamma, beta, own_dres=False):
+    """-> (dx, dres or None, dgamma, dbeta).  Without dropout the residual branch's gradient IS dx: the same tensor is
+    returned twice unless own_dres asks for a copy of its own (a caller that goes on to accumulate into one of them
+    while a side-stream weight gradient still reads the other must)."""
+    s, mean, rstd = tape['s'], tape['mean'], tape['rstd']
+    D = s.shape[-1]
+    rows = s.numel() // D
+    dx = torch.empty_like(s)
+    t = torch.empty_like(s)
+    dres = torch.empty_like(s) if tape['has_res'] and (tape['p'] > 0 or own_dres) else None
+    _lib.call('ft_layernorm_bwd', dy.data_ptr(), s.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+              dx.data_ptr(), t.data_ptr(), _p(dres), rows, D, tape['p'], tape['seed'], H._stream())
+    dg, db = _emit_multi([gamma, beta], lambda o: H.colsum2_raw(t.data_ptr(), dy.data_ptr(), D, o[0], o[1], rows, D),
+                         (t, dy), heavy='light')
+    return dx, ((dres if dres is not None else dx) if tape['has_res'] else None), dg, db
+
+
+def convbias_fwd(x, w, b, relu):
+    """nn.Conv1d(Cin, Cout, k, padding=k//2) with bias (+ ReLU) on channels-last x -> (y, tape)"""
+    B, T, Cin = x.shape
+    Cout, _, k = w.shape
+    wp = H.conv_pack_weight(w)
+    y = torch.empty(B, T, Cout, device=x.device, dtype=x.dtype)
+    _lib.call('ft_conv1d_bias_fwd', x.data_ptr(), Cin, wp.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, B, T, Cin,
+              Cout, k, int(relu), H._stream())
+    return y, dict(x=x, wp=wp, y=y if relu else None, relu=bool(relu))
+
+
+def convbias_bwd(tape, dy, w, b, need_dx=True, dx_into=None):
+    """-> (dx or None, dw, db); dx_into: an existing gradient of x that dx is ADDED onto"""
+    x, wp, y = tape['x'], tape['wp'], tape['y']
+    B, T, Cin = x.shape
+    Cout = w.shape[0]
+    if tape['relu']:
+        g = torch.empty_like(dy)
+        _lib.call('ft_relu_bwd', dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), H._stream())
+        dy = g
+    dx = None
+    if need_dx:
+        dx = dx_into if dx_into is not None else torch.empty_like(x)
+        H.conv1d_bwd_data_raw(dy.data_ptr(), Cout, wp, dx, B, T, T, T, dx_into is not None, w=w)
+    dw = _emit(w, lambda o: H.conv1d_bwd_weight_raw(dy.data_ptr(), Cout, x, o, T, T), (dy, x))
+    db = _emit(b, lambda o: H.colsum_raw(dy.data_ptr(), Cout, o, B * T, Cout), (dy,), heavy='light')
+    return dx, dw, db
 
 
 class AddLayerNormFn(Function):
@@ -147,36 +216,15 @@ class AddLayerNormFn(Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, eps, p=0.0, seed=0):
-        x = _c(x)
-        D = x.shape[-1]
-        rows = x.numel() // D
-        s = torch.empty_like(x) if res is not None else x
-        y = torch.empty_like(x)
-        mean = torch.empty(rows, device=x.device, dtype=x.dtype)
-        rstd = torch.empty(rows, device=x.device, dtype=x.dtype)
-        p = float(p) if res is not None else 0.0
-        _lib.call('ft_layernorm_fwd', x.data_ptr(), _p(_c(res) if res is not None else None), gamma.data_ptr(),
-                  beta.data_ptr(), s.data_ptr() if res is not None else None, y.data_ptr(), mean.data_ptr(),
-                  rstd.data_ptr(), rows, D, float(eps), p, int(seed), H._stream())
-        ctx.save_for_backward(s, gamma, beta, mean, rstd)
-        ctx.has_res = res is not None
-        ctx.p, ctx.seed = p, int(seed)
+        y, ctx.tape = addln_fwd(_c(x), res, gamma, beta, eps, p, seed)
+        ctx.params = (gamma, beta)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        s, gamma, beta, mean, rstd = ctx.saved_tensors
-        dy = _c(dy)
-        D = s.shape[-1]
-        rows = s.numel() // D
-        dx = torch.empty_like(s)
-        t = torch.empty_like(s)
-        dres = torch.empty_like(s) if ctx.has_res and ctx.p > 0 else None
-        _lib.call('ft_layernorm_bwd', dy.data_ptr(), s.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                  dx.data_ptr(), t.data_ptr(), _p(dres), rows, D, ctx.p, ctx.seed, H._stream())
-        dg, db = _emit_multi([gamma, beta], lambda o: H.colsum2_raw(t.data_ptr(), dy.data_ptr(), D, o[0], o[1], rows, D),
-                             heavy=False)
-        return dx, ((dres if dres is not None else dx) if ctx.has_res else None), dg, db, None, None, None
+        dx, dres, dg, db = addln_bwd(ctx.tape, _c(dy), *ctx.params)
+        ctx.tape = None
+        return dx, dres, dg, db, None, None, None
 
 
 class ConvBiasFn(Function):
@@ -184,33 +232,14 @@ class ConvBiasFn(Function):
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
-        x = _c(x)
-        B, T, Cin = x.shape
-        Cout, _, k = w.shape
-        wp = H.conv_pack_weight(w)
-        y = torch.empty(B, T, Cout, device=x.device, dtype=x.dtype)
-        _lib.call('ft_conv1d_bias_fwd', x.data_ptr(), Cin, wp.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, B, T, Cin,
-                  Cout, k, int(relu), H._stream())
-        ctx.save_for_backward(x, wp, y if relu else None, w, b)
-        ctx.relu = bool(relu)
+        y, ctx.tape = convbias_fwd(_c(x), w, b, relu)
+        ctx.params = (w, b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, wp, y, w, b = ctx.saved_tensors
-        dy = _c(dy)
-        B, T, Cin = x.shape
-        Cout = w.shape[0]
-        if ctx.relu:
-            g = torch.empty_like(dy)
-            _lib.call('ft_relu_bwd', dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), H._stream())
-            dy = g
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            H.conv1d_bwd_data_raw(dy.data_ptr(), Cout, wp, dx, B, T, T, T, False, w=w)
-        dw = _emit(w, lambda o: H.conv1d_bwd_weight_raw(dy.data_ptr(), Cout, x, o, T, T), (dy, x))
-        db = _emit(b, lambda o: H.colsum_raw(dy.data_ptr(), Cout, o, B * T, Cout), heavy=False)
+        dx, dw, db = convbias_bwd(ctx.tape, _c(dy), *ctx.params, need_dx=ctx.needs_input_grad[0])
+        ctx.tape = None
         return dx, dw, db, None
 
 
@@ -246,6 +275,235 @@ class PosEncFn(Function):
                       ws.numel(), H._stream())
 
         return dout, None, _emit(scale, dscale, heavy=False)
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole FFTBlocks per C call (include/fwdtaco_hip.h: FtFFTBlock, ft_fft_blocks_fwd / ft_fft_blocks_bwd)
+# ---------------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+_FP = _ct.c_void_p
+
+
+class _CBlock(_ct.Structure):
+    _fields_ = ([(n, _ct.c_int) for n in ('B', 'T', 'd', 'nheads', 'dfft', 'k1', 'k2')]
+                + [(n, _ct.c_float) for n in ('p_drop', 'eps1', 'eps2')]
+                + [(n, _ct.c_uint64) for n in ('seed_attn', 'seed_ln1', 'seed_ln2')]
+                + [(n, _FP) for n in ('key_pad', 'in_w', 'in_b', 'out_w', 'out_b', 'c1_wp', 'c1_b', 'c2_wp', 'c2_b', 'n1_g',
+                                      'n1_b', 'n2_g', 'n2_b', 'in_wT', 'out_wT', 'c1_wpt', 'c2_wpt', 'x', 'qkv', 'att',
+                                      'lse2', 'sa', 's1', 'mean1', 'rstd1', 'y1', 'h1', 'h2', 's2', 'mean2', 'rstd2', 'y2')])
+
+
+class _CGrads(_ct.Structure):
+    _fields_ = [(n, _FP) for n in ('dy2', 'dx', 't2', 'd_y1', 'd_h2', 'd_h1', 'g_h1', 't1', 'd_h', 'd_sa', 'datt', 'dqkv',
+                                   'g_in_w', 'g_in_b', 'g_out_w', 'g_out_b', 'g_c1_w', 'g_c1_b', 'g_c2_w', 'g_c2_b',
+                                   'g_n1_g', 'g_n1_b', 'g_n2_g', 'g_n2_b')]
+
+
+_GRAD_FIELDS = ('g_in_w', 'g_in_b', 'g_out_w', 'g_out_b', 'g_c1_w', 'g_c1_b', 'g_c2_w', 'g_c2_b', 'g_n1_g', 'g_n1_b', 'g_n2_g',
+                'g_n2_b')
+_side_ws = {}
+
+
+def _carve(buf: torch.Tensor, sizes):
+    """16-byte aligned float sub-buffers of one allocation -> (device addresses, element offsets)"""
+    base, off, out, offs = buf.data_ptr(), 0, [], []
+    for n in sizes:
+        out.append(base + 4 * off)
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    return out, offs
+
+
+def _arena(sizes, device):
+    return torch.empty(sum((n + 3) // 4 * 4 for n in sizes), device=device, dtype=torch.float32)
+
+
+def composite_ok(d: int, nheads: int) -> bool:
+    """whole blocks per C call: the bf16 mode with the fused attention (head width 64 / 128)"""
+    return (H.gemm_precision_mode() == 'bf16' and d % nheads == 0 and d // nheads in (64, 128)
+            and os.environ.get('FT_ATTN_FUSED', '1') == '1' and os.environ.get('FT_FFT_COMPOSITE', '1') == '1')
+
+
+def blocks_fwd_composite(h, key_pad, params, nhead, p, eps1, eps2, seeds):
+    """every launch of the transformer's FFTBlocks from ONE C call -> (output of the last block, state for the backward)"""
+    B, T, d = h.shape
+    R = B * T
+    n = len(params) // 12
+    f = params[4].shape[0]
+    k1, k2 = params[4].shape[2], params[6].shape[2]
+    sizes = [3 * R * d, R * d, B * nhead * T, R * d, R * d, R, R, R * d, R * f, R * d, R * d, R, R, R * d]
+    names = ('qkv', 'att', 'lse2', 'sa', 's1', 'mean1', 'rstd1', 'y1', 'h1', 'h2', 's2', 'mean2', 'rstd2', 'y2')
+    blocks = (_CBlock * n)()
+    arenas, keep = [], []
+    x_ptr = h.data_ptr()
+    for i in range(n):
+        in_w, in_b, out_w, out_b, c1w, c1b, c2w, c2b, n1g, n1b, n2g, n2b = params[12 * i:12 * i + 12]
+        ar = _arena(sizes, h.device)
+        arenas.append(ar)
+        addr, offs = _carve(ar, sizes)
+        ptrs = dict(zip(names, addr))
+        y2_off = offs[-1]
+        c1p, c2p = H.conv_pack_weight(c1w), H.conv_pack_weight(c2w)
+        keep += [c1p, c2p]
+        b = blocks[i]
+        b.B, b.T, b.d, b.nheads, b.dfft, b.k1, b.k2 = B, T, d, nhead, f, k1, k2
+        b.p_drop, b.eps1, b.eps2 = p, eps1, eps2
+        b.seed_attn, b.seed_ln1, b.seed_ln2 = seeds[3 * i], seeds[3 * i + 1], seeds[3 * i + 2]
+        b.key_pad = _p(key_pad)
+        b.in_w, b.in_b, b.out_w, b.out_b = in_w.data_ptr(), in_b.data_ptr(), out_w.data_ptr(), out_b.data_ptr()
+        b.c1_wp, b.c1_b, b.c2_wp, b.c2_b = c1p.data_ptr(), c1b.data_ptr(), c2p.data_ptr(), c2b.data_ptr()
+        b.n1_g, b.n1_b, b.n2_g, b.n2_b = n1g.data_ptr(), n1b.data_ptr(), n2g.data_ptr(), n2b.data_ptr()
+        b.x = x_ptr
+        for k_, v_ in ptrs.items():
+            setattr(b, k_, v_)
+        x_ptr = ptrs['y2']
+    _lib.call('ft_fft_blocks_fwd', _ct.byref(blocks), n, H._stream())
+    y = arenas[-1][y2_off:y2_off + R * d].view(B, T, d)          # the last block's output, in place
+    return y, dict(blocks=blocks, arenas=arenas, keep=keep, h=h, key_pad=key_pad, dims=(B, T, d, f, k1, k2, nhead))
+
+
+def blocks_bwd_composite(state, dy, params):
+    """-> (d wrt the first block's input, list of the 12 * n parameter gradients (None where a gradient sink took them))"""
+    blocks = state['blocks']
+    B, T, d, f, k1, k2, nhead = state['dims']
+    R = B * T
+    n = len(params) // 12
+    dev = dy.device
+    sizes = [R * d, R * d, R * d, R * f, R * f, R * d, R * d, R * d, R * d, 3 * R * d]
+    names = ('t2', 'd_y1', 'd_h2', 'd_h1', 'g_h1', 't1', 'd_h', 'd_sa', 'datt', 'dqkv')
+    grads = (_CGrads * n)()
+    scratch, outs, sunk = [], [None] * (12 * n), []
+    sink = ops._SINK
+    dy_ptr = dy.data_ptr()
+    last_dh = None
+    for i in range(n - 1, -1, -1):
+        ps = params[12 * i:12 * i + 12]
+        b, g = blocks[i], grads[i]
+        wit, wot = H.transpose2d(ps[0]), H.transpose2d(ps[2])
+        c1t, c2t = H.conv_pack_weight_t(ps[4]), H.conv_pack_weight_t(ps[6])
+        scratch += [wit, wot, c1t, c2t]         # (referenced until the launches that read them have been issued AND run)
+        b.in_wT, b.out_wT = wit.data_ptr(), wot.data_ptr()
+        b.c1_wpt, b.c2_wpt = c1t.data_ptr(), c2t.data_ptr()
+        ar = _arena(sizes, dev)
+        scratch.append(ar)
+        addr, offs = _carve(ar, sizes)
+        ptrs = dict(zip(names, addr))
+        for k_, v_ in ptrs.items():
+            setattr(g, k_, v_)
+        g.dy2, g.dx = dy_ptr, ptrs['d_h']
+        dy_ptr = ptrs['d_h']
+        last_dh = (ar, offs[names.index('d_h')])
+        for j, name in enumerate(_GRAD_FIELDS):
+            ent = ops._sink_view(ps[j])
+            if ent is not None:
+                sink.written.add(ent[0])        # claimed (a second emitter of the same parameter would get a fresh tensor)
+                sunk.append(ent[0])
+                setattr(g, name, ent[1].data_ptr())
+            else:
+                t = torch.empty_like(ps[j])
+                outs[12 * i + j] = t
+                setattr(g, name, t.data_ptr())
+    ws = H.workspace(_lib.query('ft_attn_workspace', B, T, nhead), dev)
+    side = sink.stream if (sink is not None and sink.stream is not None) else None
+    side_raw = side.cuda_stream if side is not None else H._stream()
+    nb = _lib.query('ft_fft_block_wgrad_workspace', B, T, d, f, k1, k2)
+    key = (dev.index or 0, side_raw)
+    wws = _side_ws.get(key)
+    if wws is None or wws.numel() < nb:
+        wws = _side_ws[key] = torch.empty(max(nb, 1 << 20), dtype=torch.uint8, device=dev)
+    _lib.call('ft_fft_blocks_bwd', _ct.byref(blocks), _ct.byref(grads), n, ws.data_ptr(), ws.numel(), wws.data_ptr(),
+              wws.numel(), H._stream(), side_raw)
+    dx = last_dh[0][last_dh[1]:last_dh[1] + R * d].view(B, T, d)     # d wrt the first block's input, in place
+    if sink is None:
+        dx._ft_keep = (scratch, state['arenas'], state['keep'])       # no sink: everything ran on this stream, in order
+    if sink is not None:
+        sink.keep.append((scratch, state['arenas'], state['keep'], dy))     # read by the weight-gradient stream until joined
+        if side is not None:
+            sink.used.add(side)
+        for idx in sunk:
+            sink.used.add(torch.cuda.current_stream())
+            if sink.on_write is not None:
+                sink.on_write(idx)
+    return dx, outs
+
+
+class TransformerFn(Function):
+    """A whole ForwardTransformer (common_layers.py:188-223: positional encoding + dropout, `layers` FFTBlocks, final
+    LayerNorm) as ONE autograd node.  Same kernels, same order, same dropout seeds as the per-layer Functions above; what
+    goes away is the host side: ~6 autograd nodes per block forward and as many Python backward calls through the
+    engine (a FastPitch step was 130 nodes and 14.7 ms of host time for 15 ms of GPU work) -- and the gradient joins of
+    the two residual connections, which autograd did with two element-wise adds per block, are now the accumulate
+    epilogues of the data-gradient GEMMs that produce the second addend.
+    args: x, key_pad, pe, pe_scale, norm_g, norm_b, then 12 tensors per block (in_w, in_b, out_w, out_b, conv1 w, b,
+    conv2 w, b, norm1 g, b, norm2 g, b); cfg = (nhead, p_block, p_posenc, training, eps1, eps2, eps_final)."""
+
+    @staticmethod
+    def forward(ctx, x, key_pad, pe, pe_scale, norm_g, norm_b, cfg, *params):
+        nhead, p_blk, p_pe, training, eps1, eps2, eps_f = cfg
+        x = _c(x)
+        B, T, D = x.shape
+        check_posenc_length(T, pe)
+        h = torch.empty_like(x)
+        _lib.call('ft_posenc_fwd', x.data_ptr(), pe.data_ptr(), pe_scale.data_ptr(), h.data_ptr(), B, T, D, H._stream())
+        pe_seed = 0
+        if training and p_pe > 0:
+            pe_seed = _seed()
+            h = H.dropout(h, p_pe, pe_seed)
+        p = p_blk if training else 0.0
+        tapes = []
+        ctx.comp = None
+        if composite_ok(D, nhead) and len(params) >= 12:
+            seeds = [(_seed() if p > 0 else 0) for _ in range(3 * (len(params) // 12))]
+            h, ctx.comp = blocks_fwd_composite(h, key_pad, params, nhead, p, eps1, eps2, seeds)
+            params_loop = ()
+        else:
+            params_loop = params
+        for i in range(len(params_loop) // 12):
+            in_w, in_b, out_w, out_b, c1w, c1b, c2w, c2b, n1g, n1b, n2g, n2b = params[12 * i:12 * i + 12]
+            s0 = _seed() if p > 0 else 0
+            sa, t_mha = mha_fwd(h, key_pad, in_w, in_b, out_w, out_b, nhead, p, s0)
+            y1, t_n1 = addln_fwd(h, sa, n1g, n1b, eps1, p, _seed() if p > 0 else 0)
+            h1, t_c1 = convbias_fwd(y1, c1w, c1b, True)
+            h2, t_c2 = convbias_fwd(h1, c2w, c2b, False)
+            h, t_n2 = addln_fwd(y1, h2, n2g, n2b, eps2, p, _seed() if p > 0 else 0)
+            tapes.append((t_mha, t_n1, t_c1, t_c2, t_n2))
+        y, t_f = addln_fwd(h, None, norm_g, norm_b, eps_f)
+        ctx.tapes, ctx.t_f, ctx.params = tapes, t_f, params
+        ctx.head = (pe, pe_scale, norm_g, norm_b, p_pe if training else 0.0, pe_seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pe, pe_scale, norm_g, norm_b, p_pe, pe_seed = ctx.head
+        params = ctx.params
+        grads = [None] * len(params)
+        d, _, g_ng, g_nb = addln_bwd(ctx.t_f, _c(dy), norm_g, norm_b)
+        if ctx.comp is not None:
+            d, grads = blocks_bwd_composite(ctx.comp, d, params)
+            ctx.comp = None
+        for i in range(len(ctx.tapes) - 1, -1, -1):
+            in_w, in_b, out_w, out_b, c1w, c1b, c2w, c2b, n1g, n1b, n2g, n2b = params[12 * i:12 * i + 12]
+            t_mha, t_n1, t_c1, t_c2, t_n2 = ctx.tapes[i]
+            with ops.batched_side_launches():       # the block's six weight / six bias gradients: one side-stream hand-over
+                d_y1, d_h2, g_n2g, g_n2b = addln_bwd(t_n2, d, n2g, n2b, own_dres=True)
+                d_h1, g_c2w, g_c2b = convbias_bwd(t_c2, d_h2, c2w, c2b)
+                d_y1, g_c1w, g_c1b = convbias_bwd(t_c1, d_h1, c1w, c1b, dx_into=d_y1)          # + the residual path
+                d_h, d_sa, g_n1g, g_n1b = addln_bwd(t_n1, d_y1, n1g, n1b, own_dres=True)
+                d, g_iw, g_ib, g_ow, g_ob = mha_bwd(t_mha, d_sa, in_w, in_b, out_w, out_b, dx_into=d_h)   # + the residual path
+            grads[12 * i:12 * i + 12] = [g_iw, g_ib, g_ow, g_ob, g_c1w, g_c1b, g_c2w, g_c2b, g_n1g, g_n1b, g_n2g, g_n2b]
+        ctx.tapes = None
+        if p_pe > 0:
+            d = H.dropout(d, p_pe, pe_seed)
+        B, T, D = d.shape
+
+        def dscale(o):
+            ws = H.workspace(_lib.query('ft_posenc_workspace'), d.device)
+            _lib.call('ft_posenc_bwd_scale', d.data_ptr(), pe.data_ptr(), o.data_ptr(), B, T, D, ws.data_ptr(),
+                      ws.numel(), H._stream())
+
+        g_scale = _emit(pe_scale, dscale, heavy=False)
+        return (d if ctx.needs_input_grad[0] else None, None, None, g_scale, g_ng, g_nb, None, *grads)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -320,10 +578,23 @@ class ForwardTransformer(nn.Module):
         key_pad = None
         if src_pad_mask is not None:
             key_pad = src_pad_mask.to(torch.uint8).contiguous()
-        x = self.pos_encoder(x)
-        for layer in self.layers:
-            x = layer(x, key_pad)
-        return AddLayerNormFn.apply(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        if os.environ.get('FT_TRANSFORMER_NODE', '1') != '1':        # one autograd node per operation (as until round 3)
+            x = self.pos_encoder(x)
+            for layer in self.layers:
+                x = layer(x, key_pad)
+            return AddLayerNormFn.apply(x, None, self.norm.weight, self.norm.bias, self.norm.eps)
+        if x.shape[1] > self.pos_encoder.pe.shape[0]:
+            raise _lib.FtError(f'sequence length {x.shape[1]} exceeds PositionalEncoding max_len '
+                               f'{self.pos_encoder.pe.shape[0]}')
+        flat = []
+        for l in self.layers:
+            a = l.self_attn
+            flat += [a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, l.conv1.weight, l.conv1.bias,
+                     l.conv2.weight, l.conv2.bias, l.norm1.weight, l.norm1.bias, l.norm2.weight, l.norm2.bias]
+        l0 = self.layers[0]
+        cfg = (l0.nhead, l0.p, self.pos_encoder.p, self.training, l0.norm1.eps, l0.norm2.eps, self.norm.eps)
+        return TransformerFn.apply(x, key_pad, self.pos_encoder.pe, self.pos_encoder.scale, self.norm.weight,
+                                   self.norm.bias, cfg, *flat)
 
 
 class SeriesPredictor(nn.Module):

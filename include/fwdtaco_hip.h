@@ -451,6 +451,43 @@ int ft_attn_bwd(const float* qkv, const float* att, const float* datt, const uns
                 float* dqkv, int B, int T, int nheads, int hd, float scale, float p_drop, uint64_t seed, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ---- a whole FFTBlock per call (common_layers.py:148-185), bf16 matmul mode with the fused attention ------------ */
+/* The FastPitch step is ~900 launches for ~13 ms of GPU work: issued one entry point at a time from Python it is bound by
+ * the host (15 us per launch).  These two calls issue every launch of n consecutive FFTBlocks -- forward: in-projection,
+ * ft_attn_fwd, out-projection, add + LayerNorm, conv1 + ReLU, conv2, add + LayerNorm; backward: the reverse, with the
+ * two residual joins as accumulate epilogues, then the blocks' weight / bias / LayerNorm gradients on wgrad_stream behind
+ * one event -- from C.  All buffers are the caller's; rows = B*T, row-major.  Same kernels, same order, same results as
+ * the single entry points above. */
+typedef struct FtFFTBlock {
+  int B, T, d, nheads, dfft, k1, k2;
+  float p_drop, eps1, eps2;
+  uint64_t seed_attn, seed_ln1, seed_ln2;
+  const unsigned char* key_pad;                  /* [B,T] or NULL */
+  /* parameters: torch layouts, the convolutions as tap-major packs [k][Cout][Cin] */
+  const float *in_w, *in_b, *out_w, *out_b, *c1_wp, *c1_b, *c2_wp, *c2_b, *n1_g, *n1_b, *n2_g, *n2_b;
+  /* backward only: W^T of the two projections and the transposed packs [k][Cin][Cout] (data gradients in the NT form) */
+  const float *in_wT, *out_wT, *c1_wpt, *c2_wpt;
+  /* activations: x [rows,d] in; the forward writes the rest, the backward reads them */
+  const float* x;
+  float *qkv, *att, *lse2, *sa, *s1, *mean1, *rstd1, *y1, *h1, *h2, *s2, *mean2, *rstd2, *y2;
+} FtFFTBlock;
+typedef struct FtFFTBlockGrads {
+  const float* dy2;                              /* d(y2) [rows,d] */
+  float* dx;                                     /* out: d(x) [rows,d] */
+  /* scratch, kept by the caller until wgrad_stream has been joined: [rows,d] each except d_h1 / g_h1 [rows,dfft] and
+   * dqkv [rows,3d] */
+  float *t2, *d_y1, *d_h2, *d_h1, *g_h1, *t1, *d_h, *d_sa, *datt, *dqkv;
+  /* parameter gradients, overwritten (torch layouts) */
+  float *g_in_w, *g_in_b, *g_out_w, *g_out_b, *g_c1_w, *g_c1_b, *g_c2_w, *g_c2_b, *g_n1_g, *g_n1_b, *g_n2_g, *g_n2_b;
+} FtFFTBlockGrads;
+int ft_fft_blocks_fwd(const FtFFTBlock* blocks, int n, void* stream);
+/* workspace: >= ft_attn_workspace(B,T,nheads) bytes (main stream); wgrad_workspace: >= ft_fft_block_wgrad_workspace(...)
+ * bytes (used on wgrad_stream only).  wgrad_stream may equal stream. */
+size_t ft_fft_block_wgrad_workspace(int B, int T, int d, int dfft, int k1, int k2);
+int ft_fft_blocks_bwd(const FtFFTBlock* blocks, const FtFFTBlockGrads* grads, int n, void* workspace,
+                      size_t workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, void* stream,
+                      void* wgrad_stream);
+
 /* ---- mel inversion + Griffin-Lim (utils/dsp.py:80-94 DSP.griffinlim ; gen_forward.py:109-116) ------------ */
 /* The DFTs are GEMMs on ft_linear_fwd (frames read in place out of the zero-padded signal with ldx = hop); these are
  * the element-wise / gather pieces.  Complex spectra are split [N][2*Fp] = Re | Im, Fp = F rounded up to 4.
