@@ -233,8 +233,6 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream);
 int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,
                          hipStream_t stream);
-// ft_planes.hip: planes pointer for a B operand (first row / k chunk of the launch) or nullptr
-const void* ft_planes_lookup(const float* b, long ldb, long rows_needed);
 // ft_capi_core.hip: workgroup slots (2 per usable CU) of a stream -- 512 unless it is CU-limited
 void ft_note_stream_slots(hipStream_t s, int slots);
 int ft_stream_slots(hipStream_t s);

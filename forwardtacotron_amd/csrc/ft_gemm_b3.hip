@@ -329,13 +329,9 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
 // B row per stage (two float4 each, k0 + 4h and k0 + 8 + 4h so the wave's two loads are 32 contiguous bytes per row);
 // the k ORDER inside a stage is therefore permuted, identically for A and B, which a dot product does not see.
 //
-// BP = true: the B operand of EVERY task of the launch is a weight matrix whose bf16 pieces already exist in memory
-// ("planes", ft_planes.hip: [row][16-k chunk][hi | mid | lo][16 k in this kernel's LDS order], 96 B per row and chunk,
-// written once per step by the split definition above, so the products are bit-identical).  A thread then stages its
-// half of a B row with three 16-B loads (one for NP = 1: rn(x) IS the hi piece) and three ds_write_b128 -- no VALU -- where
-// every one of the M / 128 row tiles of the launch used to split the same weights again.  T.B points at the planes of the
-// task's first row / k chunk; row and tap strides follow from ldb and b_tap_stride.
-template <int NP, bool BP>
+// (A variant that staged pre-split weight operands -- split once per step instead of by every row tile -- was built in
+// round 2, bit-identical and SLOWER: 0.320 -> 0.340 ms on the postnet bank; removed in round 3, lab/NOTES.md.)
+template <int NP>
 __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch batch) {
   constexpr int TM = 2, TN = 2, BM = 128, BN = 128, SK = 16;
   constexpr int RW = NP == 3 ? 48 : 24;            // row stride, bf16 elements
@@ -389,7 +385,6 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   bool a_ok;
   unsigned a_voff, vb, vbad0, vbad1;                 // bit 31 of a voffset = out of range = the load returns zeros
   unsigned va0, va1, vb0, vb1;                       // the voffsets of the stage under the cursor (two 16-B loads per row)
-  long btapb = 0;                                    // BP: bytes between the planes of consecutive taps
   bool ktail;                                        // K is not a multiple of the stage depth: the last chunk is masked
   const float* tapA;                                 // descriptor bases per (task, tap); the k position of a stage goes
   const float* tapB;                                 // into soffset
@@ -399,10 +394,8 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   auto mask_tail = [&]() {
     va0 |= vbad0;
     va1 |= vbad1;
-    if constexpr (!BP) {                             // planes are zero-filled up to the next multiple of 16 k
-      vb0 |= vbad0;
-      vb1 |= vbad1;
-    }
+    vb0 |= vbad0;
+    vb1 |= vbad1;
   };
   auto set_tap = [&]() {
     const int shift = shift0 + l_tap * sstep;
@@ -413,8 +406,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     vb1 = vb + 32u;
     if (ktail && kch == 1) mask_tail();
     tapA = a_base + (long)shift * atst * lda;
-    if constexpr (BP) tapB = reinterpret_cast<const float*>(reinterpret_cast<const char*>(b_base) + (long)l_tap * btapb);
-    else tapB = b_base + (long)l_tap * btap;
+    tapB = b_base + (long)l_tap * btap;
   };
   auto setup = [&](const FtGemmTask& S, const float* SA, const float* SB) {
     tK = S.K;
@@ -438,15 +430,8 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     const int b = m / Tlog;
     a_t = m - b * Tlog;
     a_voff = (unsigned)((((long)b * abst + (long)a_t * atst) - row0) * lda * 4) + 16u * h;
-    if constexpr (BP) {
-      const long rowb = (long)((S.ldb + 15) / 16) * 96;                       // bytes of one planes row
-      b_base = reinterpret_cast<const float*>(reinterpret_cast<const char*>(SB) + (long)n0 * rowb);
-      vb = n0 + rr < tN ? (unsigned)((long)rr * rowb) + 16u * h : OOB;
-      btapb = (S.b_tap_stride / S.ldb) * rowb;
-    } else {
-      b_base = SB + (long)n0 * S.ldb;
-      vb = n0 + rr < tN ? (unsigned)((long)rr * S.ldb * 4) + 16u * h : OOB;
-    }
+    b_base = SB + (long)n0 * S.ldb;
+    vb = n0 + rr < tN ? (unsigned)((long)rr * S.ldb * 4) + 16u * h : OOB;
     const int kl = (kch - 1) * SK;                   // only the last k chunk of a tap can reach past K
     ktail = tK % SK != 0;
     vbad0 = kl + 4 * h < tK ? 0u : OOB;
@@ -477,17 +462,8 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(l_kc * SK * 4);
     R.a0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va0, soff, 0);
     R.a1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, va1, soff, 0);
-    if constexpr (BP) {
-      const unsigned soffb = (unsigned)__builtin_amdgcn_readfirstlane(l_kc * 96);
-      R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0, soffb, 0);                   // hi
-      if constexpr (NP == 3) {
-        R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb1, soffb, 0);                 // mid (vb + 32)
-        R.b2 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0 + 64u, soffb, 0);           // lo
-      }
-    } else {
-      R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0, soff, 0);
-      R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb1, soff, 0);
-    }
+    R.b0 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb0, soff, 0);
+    R.b1 = __builtin_amdgcn_raw_buffer_load_b128(rsB, vb1, soff, 0);
     __builtin_amdgcn_sched_barrier(0);              // keep the requests at the top of the iteration (hipcc sinks them to
   };                                                // the bottom otherwise: zero prefetch distance)
   auto advance = [&]() {
@@ -522,16 +498,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   };
   auto store_stage = [&](const Regs& R, unsigned short* buf) {
     put8(buf + rr * RW + 8 * h, R.a0, R.a1);
-    if constexpr (BP) {
-      unsigned short* row = buf + (BM + rr) * RW + 8 * h;
-      *reinterpret_cast<u32x4*>(row) = R.b0;
-      if constexpr (NP == 3) {
-        *reinterpret_cast<u32x4*>(row + 16) = R.b1;
-        *reinterpret_cast<u32x4*>(row + 32) = R.b2;
-      }
-    } else {
-      put8(buf + (BM + rr) * RW + 8 * h, R.b0, R.b1);
-    }
+    put8(buf + (BM + rr) * RW + 8 * h, R.b0, R.b1);
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -553,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
 #pragma unroll
     for (int i = 0; i < TM * TN * (NP == 3 ? 6 : 1); ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? (BP ? 3 : 5) : (BP ? 4 : 8), 0);   // VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? 5 : 8, 0);   // VALU
     }
   };
   // TWO fragment sets: the fragments of stage c+1 are read during the MFMAs of stage c (from the buffer the barrier at
@@ -1199,33 +1166,8 @@ int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStr
     span_ok = span_ok && ts >= 0 && bs >= 0 && rows * t.lda * 4 < (1L << 31) && 128L * t.ldb * 4 < (1L << 31);
   }
   if (big && pipelined && span_ok) {
-    // weights whose bf16 pieces were prepared this step (ft_planes.hip): if EVERY task's B operand has them, the launch
-    // stages B without splitting (BP = true).  Same bits either way.
-    const void* pl[FT_MAX_TASKS];
-    bool planes = true;
-    const int nt = batch.t[0].nz > 1 ? 1 : (ntask < FT_MAX_TASKS ? ntask : FT_MAX_TASKS);
-    for (int i = 0; i < nt && planes; ++i) {
-      const FtGemmTask& t = batch.t[i];
-      const long rows_per_tap = t.ldb > 0 ? t.b_tap_stride / t.ldb : 0;
-      planes = t.nz <= 1 && t.ldb > 0 && (t.taps <= 1 || (t.b_tap_stride > 0 && t.b_tap_stride % t.ldb == 0)) &&
-               128L * ((t.ldb + 15) / 16) * 96 < (1L << 31);
-      if (!planes) break;
-      pl[i] = ft_planes_lookup(t.B, t.ldb, (long)(t.taps - 1) * rows_per_tap + t.N);      // null at once while the mechanism is off
-      planes = pl[i] != nullptr;
-    }
-    FtGemmBatch pb;
-    if (planes) {                                      // (the 4 KB descriptor is only copied for a launch that uses planes)
-      pb = batch;
-      for (int i = 0; i < nt; ++i) pb.t[i].B = static_cast<const float*>(pl[i]);
-    }
-    if (planes) {
-      if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1, true>), grid, dim3(256), 0, stream, pb);
-      else hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3, true>), grid, dim3(256), 0, stream, pb);
-    } else if (bf16) {
-      hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1, false>), grid, dim3(256), 0, stream, batch);
-    } else {
-      hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3, false>), grid, dim3(256), 0, stream, batch);
-    }
+    if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1>), grid, dim3(256), 0, stream, batch);
+    else hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3>), grid, dim3(256), 0, stream, batch);
   } else if (big) {
     if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 1>), grid, dim3(256), 0, stream, batch);
     else hipLaunchKernelGGL((ft_gemm_rows_b3_kernel<2, 2, 3>), grid, dim3(256), 0, stream, batch);

@@ -1,6 +1,5 @@
-// The exact three-way bf16 split of fp32 operands, shared by the GEMM kernels that split while staging
-// (ft_gemm_b3.hip) and the once-per-step split of weight matrices (ft_planes.hip): ONE definition, so that pre-split
-// operands give the same bits as operands split in the kernel.
+// The exact three-way bf16 split of fp32 operands of the GEMM kernels that split while staging (ft_gemm_b3.hip): ONE
+// definition for every place a value is split.
 #pragma once
 #include "ft_common.h"
 

@@ -6,7 +6,6 @@ tensors and raise if handed anything else -- there is no fallback path.
 """
 import contextlib
 import ctypes
-import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -307,61 +306,14 @@ class PackCache:
                 add(w2[32 * j:32 * j + 32], pack[64 * j + 32:64 * j + 64], None, 32, C, 1)
         self.n, self.tiles = len(descs), tiles
         self.descs = torch.frombuffer(bytearray(b''.join(descs)), dtype=torch.uint8).to(device) if descs else None
-        # bf16 pieces ("planes", include/fwdtaco_hip.h: ft_planes_*) of every matrix a GEMM may take as its B operand:
-        # the raw 2-D weights (forward of a Linear), their transposes (its data gradient), the tap-major conv / bank packs
-        # and their transposes.  Registered with the library when this cache becomes the one in use; the library splits
-        # only those a launch really asked for.
-        self._plane_mats = []
-        for w in mats:
-            self._plane_mats.append((w, w.shape[0], w.shape[1]))
-            wt = self.t2d[(w.data_ptr(), w.shape[0], w.shape[1])]
-            self._plane_mats.append((wt, wt.shape[0], wt.shape[1]))
-        for wp in list(self.wp.values()) + list(self.wpt.values()):
-            self._plane_mats.append((wp, wp.shape[0] * wp.shape[1], wp.shape[2]))
-        for ws in banks:
-            C, Cin = ws[0].shape[0], ws[0].shape[1]
-            wp_all, wpt_all = self.bank[tuple(w.data_ptr() for w in ws)]
-            self._plane_mats.append((wp_all, wp_all.numel() // Cin, Cin))
-            self._plane_mats.append((wpt_all, wpt_all.numel() // C, C))
-        self._plane_mats = [(w, r, c) for w, r, c in self._plane_mats
-                            if r >= 128 and c >= 16 and c % 4 == 0 and w.data_ptr() % 16 == 0]
-        self._planes = None             # allocated when the mechanism is first found switched on (it is off by default)
-        self._device = device
-
-    def _own_planes(self) -> None:
-        global _planes_owner
-        if self._planes is None:
-            self._planes = [torch.empty(_lib.query('ft_planes_bytes', r, c), dtype=torch.uint8, device=self._device)
-                            for _, r, c in self._plane_mats]
-        if _planes_owner is None or _planes_owner() is not self:
-            _lib.call('ft_planes_clear')
-            for (w, r, c), buf in zip(self._plane_mats, self._planes):
-                _lib.call('ft_planes_register', w.data_ptr(), r, c, buf.data_ptr())
-            _planes_owner = weakref.ref(self)       # weak: a dropped cache must reach __del__, which clears the registry
 
     def refresh(self) -> None:
         if self.n:
             _lib.call('ft_pack_weights', _p(self.descs), self.n, self.tiles, _stream())
-        if _lib.query('ft_planes_enable', -1):
-            self._own_planes()
-            _lib.call('ft_planes_refresh', _stream())
 
     @staticmethod
     def release() -> None:
-        """the weights are about to change (or the step failed): every plane is stale until the next refresh()"""
-        _lib.call('ft_planes_invalidate')
-
-    def __del__(self):
-        global _planes_owner
-        try:                                # the registry must not outlive the buffers (and weights) it points at
-            if _planes_owner is not None and _planes_owner() in (self, None):
-                _planes_owner = None
-                _lib.call('ft_planes_clear')
-        except Exception:
-            pass
-
-
-_planes_owner = None
+        """the weights are about to change (or the step failed): the packs are stale until the next refresh()"""
 
 
 pack_cache: Optional[PackCache] = None

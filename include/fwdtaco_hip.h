@@ -21,7 +21,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define FWDTACO_ABI_VERSION 3
+#define FWDTACO_ABI_VERSION 4
 
 #ifdef __cplusplus
 extern "C" {
@@ -91,26 +91,6 @@ typedef struct FtPackDesc {
   int d0, d1, k, reserved;
 } FtPackDesc;
 int ft_pack_weights(const FtPackDesc* descs, int n, long total_tiles, void* stream);
-/* Pre-split weight operands ("planes") for the 128x128 NT GEMM behind ft_linear_fwd / ft_conv1d_fwd / ft_conv_bank_fwd
- * and their data gradients -- the B operand of nn.Linear / nn.Conv1d, i.e. the weights (common_layers.py:47,
- * forward_tacotron.py:80-89).  That GEMM computes fp32 products as exact three-way bf16 splits; every row tile of a
- * launch used to split the same weights again.  The owner of a weight matrix w [rows][ld] (fp32, ld % 4 == 0; a raw
- * 2-D weight, its transpose, a tap-major conv pack) registers it with a buffer of ft_planes_bytes(rows, ld) bytes;
- * ft_planes_refresh -- once per step, after the weights' packs are current -- splits, in ONE launch, every registered
- * matrix that a GEMM launch has asked for since registration; ft_planes_invalidate declares all planes stale (the
- * optimizer is about to change the weights; until the next refresh every launch splits in the kernel again).  A launch
- * gives the same bits with or without planes (one split definition): only the time differs.  OFF by default -- measured
- * slower than splitting in the kernel (ft_planes.hip) -- FT_GEMM_PLANES=1 or ft_planes_enable(1) turn the mechanism on
- * (ft_planes_enable returns the previous setting; a negative argument only queries).  ft_planes_clear forgets all
- * registrations (buffers stay the caller's). */
-int ft_planes_enable(int on);
-size_t ft_planes_bytes(long rows, long ld);
-int ft_planes_register(const float* w, long rows, long ld, void* planes);
-int ft_planes_refresh(void* stream);
-int ft_planes_invalidate(void);
-int ft_planes_clear(void);
-/* launches served from planes / launches that found a registered but stale matrix, registered / wanted matrices */
-int ft_planes_counters(long* hits, long* misses, long* registered, long* wanted);
 int ft_conv1d_fwd(const float* x, long ldx, const float* wp, const float* scale, const float* shift, float* y,
                   long ldy, int B, int T, int Cin, int Cout, int k, int Tout, int relu, int accumulate,
                   void* stream);

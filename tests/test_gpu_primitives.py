@@ -378,68 +378,6 @@ def test_bank_bn_pool_fused_equals_three_passes(H, B, T, Cin, C, K):
     # (the gradients' parity with the reference is pinned end to end: tests/test_gpu_model.py's golden train steps)
 
 
-def _planes_counters():
-    import ctypes
-    from forwardtacotron_amd import _lib
-    v = [ctypes.c_long(0) for _ in range(4)]
-    _lib.call('ft_planes_counters', *[ctypes.byref(x) for x in v])
-    return [x.value for x in v]         # hits, misses, registered, wanted
-
-
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
-def test_presplit_weight_planes_give_the_same_bits(H, mode):
-    """ft_planes_*: the 128x128 NT GEMM fed with weights split ONCE per step (planes) must give the same bits as the
-    same launch splitting in the kernel -- Linear forward (raw weight), its data gradient (transposed weight), a k-tap
-    conv (tap-major pack, K = 88: a zero-filled chunk tail), a conv bank (members at row offsets inside one pack) and the
-    bank's chained data gradient -- in the fp32-exact and the bf16 mode.  A matrix is only split once a launch has asked
-    for it; after release() nothing is served from planes.  (The mechanism is off by default: measured slower, ft_planes.hip.)"""
-    g = torch.Generator().manual_seed(5)
-    Bn, T = 32, 400                                  # 12 800 rows = 100 row tiles: every launch below takes the 128x128 kernel
-    w = dev(torch.randn(256, 256, generator=g) * 0.1)
-    cw = dev(torch.randn(256, 88, 5, generator=g) * 0.2)
-    bank = [dev(torch.randn(128, 256, k, generator=g) * 0.1) for k in range(1, 4)]
-    x = dev(torch.randn(Bn, T, 256, generator=g))
-    x88 = dev(torch.randn(Bn, T, 88, generator=g))
-    dy = dev(torch.randn(Bn, T, 256, generator=g))
-    dyb = dev(torch.randn(Bn, T + 1, 3 * 128, generator=g))
-    from forwardtacotron_amd import _lib
-    old = H.set_gemm_precision(mode)
-    was_on = _lib.query('ft_planes_enable', 1)       # off by default (measured slower): on for this test
-    cache = H.PackCache([w], [cw], [bank], w.device)
-
-    def run():
-        wp = H.conv_pack_weight(cw)
-        return [H.linear_fwd(x, w), H.linear_bwd_data(dy, w), H.conv1d_fwd(x88, wp, True),
-                H.conv_bank_fwd(x, H.bank_packs(bank, False), 3, 128, True, T + 1),
-                H.conv_bank_bwd_data(dyb, H.bank_packs(bank, False), 3, 128, 256, T, ws=bank)]
-
-    try:
-        ref = run()                                  # no cache: packs on the fly, split in the kernel
-        H.pack_cache = cache
-        cache.refresh()
-        h0, m0, reg, _ = _planes_counters()
-        assert reg >= 6
-        first = run()                                # registered but never asked for: not split yet -> misses
-        h1, m1, _, wanted = _planes_counters()
-        assert h1 == h0 and m1 > m0 and wanted >= 4
-        cache.refresh()                              # splits what was asked for
-        second = run()
-        h2, m2, _, _ = _planes_counters()
-        assert h2 - h1 >= 5 and m2 == m1             # every launch above served from planes (the bank: one per member)
-        torch.cuda.synchronize()
-        for a, b, c in zip(ref, first, second):
-            assert torch.equal(a, b) and torch.equal(a, c)
-        cache.release()
-        third = run()
-        h3, _, _, _ = _planes_counters()
-        assert h3 == h2
-        for a, b in zip(ref, third):
-            assert torch.equal(a, b)
-    finally:
-        H.pack_cache = None
-        cache.release()
-        H.set_gemm_precision(old)
-        _lib.query('ft_planes_enable', was_on)
 
 
 def test_non_recurrent_entry_points_are_graph_capturable(H):
