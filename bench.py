@@ -39,7 +39,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide; AMD's 5 PF
 HBM_PEAK_TBS = 8.0                # HBM3E spec (6.3 TB/s achievable per the guide)
 
 BANK_SHAPE = (32, 841, 80, 256, 8)      # B, T, Cin, C, K of the postnet conv bank forward at the benchmark config
-TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_bank_fwd.json')    # written by tools/pmc_traffic.py from --pmc passes
+TRAFFIC_FILE = os.path.join('profiles', 'r03_pmc_bank_fwd.json')    # written by tools/pmc_traffic.py from --pmc passes
 
 
 class Probes:
@@ -329,6 +329,10 @@ def main():
         if rehearsal:
             dist.init_process_group('gloo')
         else:
+            # a collective's workgroups hold CUs the persistent recurrences' grids may be waiting for (they retire on
+            # their own -- a 24 MB bucket is < 1 ms against a spin bound of >= 100 ms -- so this is about delay, not
+            # faults): at most 16 of the 256 CUs, which still drives all seven xGMI links
+            os.environ.setdefault('NCCL_MAX_NCHANNELS', '16')
             dist.init_process_group('nccl', device_id=device)
 
     from forwardtacotron_amd import data
@@ -444,6 +448,9 @@ def main():
                                      'same parity bars, FT_GEMM_B3=0 switches it off)'},
             'per_gpu': round(value / world, 1), 'loss': round(loss, 5), 'rnn_persistent': rnn_persistent,
             'rnn_launches': {'persistent': pers, 'per_step_fallback': refused, 'waited_for_other_stream': _hip.rnn_waited_launches()},
+            # (direction, batch group) groups of the persistent launches since load: hand-off through their XCD's L2 /
+            # on the agent-scope protocol (placement is verified inside each kernel, ft_rnn_mode_counts)
+            'rnn_modes': dict(zip(('xcd_local_groups', 'agent_scope_groups'), _hip.rnn_mode_counts())),
             'roofline': roof,
         }
         if world == 1 and not args.no_variants:

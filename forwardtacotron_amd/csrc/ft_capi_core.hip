@@ -432,11 +432,29 @@ int ft_conv_bank_fwd_stats(const float* x, long ldx, const float* wp_all, float*
   return ft_check_launch("conv_bank_fwd_stats");
 }
 
+static int conv1d_bwd_data_impl(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
+                                int Cout, int k, int Tbuf, int Tvalid, int accumulate, int wp_transposed,
+                                const float* relu_mask, void* stream);
+
 int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
                        int Cout, int k, int Tbuf, int Tvalid, int accumulate, int wp_transposed, void* stream) {
+  return conv1d_bwd_data_impl(dy, lddy, wp, dx, lddx, B, T, Cin, Cout, k, Tbuf, Tvalid, accumulate, wp_transposed, nullptr,
+                              stream);
+}
+
+int ft_conv1d_bwd_data_relu(const float* dy, long lddy, const float* wp, const float* y, float* dx, long lddx, int B,
+                            int T, int Cin, int Cout, int k, int wp_transposed, void* stream) {
+  FT_REQUIRE(y != nullptr, "conv1d_bwd_data_relu: null mask source");
+  return conv1d_bwd_data_impl(dy, lddy, wp, dx, lddx, B, T, Cin, Cout, k, T, T, 0, wp_transposed, y, stream);
+}
+
+static int conv1d_bwd_data_impl(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
+                                int Cout, int k, int Tbuf, int Tvalid, int accumulate, int wp_transposed,
+                                const float* relu_mask, void* stream) {
   FT_REQUIRE(k >= 1 && Tvalid <= Tbuf, "conv1d_bwd_data: bad k/Tvalid");
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
+  b.relu_mask = relu_mask;
   FtGemmTask& t = b.t[0];
   t.A = dy; t.B = wp; t.C = dx;
   t.lda = lddy; t.ldb = wp_transposed ? Cout : Cin; t.ldc = lddx; t.b_tap_stride = (long)Cout * Cin;

@@ -49,8 +49,8 @@ int block_bwd_data(const FtFFTBlock& b, const FtFFTBlockGrads& g, void* ws, size
   // y2 = LN2(y1 + drop(h2)): d_y1 (residual path), d_h2 (own buffer: conv1's data gradient is accumulated into d_y1 while
   // conv2's weight gradient still reads d_h2 on the other stream)
   FT_TRY(ft_layernorm_bwd(g.dy2, b.s2, b.n2_g, b.mean2, b.rstd2, g.d_y1, g.t2, g.d_h2, rows, d, b.p_drop, b.seed_ln2, st));
-  FT_TRY(ft_conv1d_bwd_data(g.d_h2, d, b.c2_wpt, g.d_h1, f, b.B, b.T, f, d, b.k2, b.T, b.T, 0, 1, st));
-  FT_TRY(ft_relu_bwd(g.d_h1, b.h1, g.g_h1, (long)rows * f, st));
+  // conv2's data gradient through conv1's ReLU: the mask is the GEMM's epilogue (g.d_h1 is not used any more)
+  FT_TRY(ft_conv1d_bwd_data_relu(g.d_h2, d, b.c2_wpt, b.h1, g.g_h1, f, b.B, b.T, f, d, b.k2, 1, st));
   FT_TRY(ft_conv1d_bwd_data(g.g_h1, f, b.c1_wpt, g.d_y1, d, b.B, b.T, d, f, b.k1, b.T, b.T, 1, 1, st));     // += residual path
   FT_TRY(ft_layernorm_bwd(g.d_y1, b.s1, b.n1_g, b.mean1, b.rstd1, g.d_h, g.t1, g.d_sa, rows, d, b.p_drop, b.seed_ln1, st));
   FT_TRY(ft_linear_bwd_data(g.d_sa, d, b.out_wT, g.datt, d, rows, d, d, 0, 0, 0, 1, st));
@@ -64,18 +64,25 @@ int block_bwd_data(const FtFFTBlock& b, const FtFFTBlockGrads& g, void* ws, size
   return FT_OK;
 }
 
-// the parameter gradients of one block (weight-gradient stream)
-int block_bwd_params(const FtFFTBlock& b, const FtFFTBlockGrads& g, void* ws, size_t wsb, void* st) {
+// the weight gradients of one block (weight-gradient stream: four split-K GEMMs)
+int block_bwd_weights(const FtFFTBlock& b, const FtFFTBlockGrads& g, void* ws, size_t wsb, void* st) {
+  const int rows = b.B * b.T, d = b.d, f = b.dfft;
+  FT_TRY(ft_conv1d_bwd_weight(g.d_h2, d, b.h1, f, g.g_c2_w, b.B, b.T, f, d, b.k2, b.T, b.T, ws, wsb, st));
+  FT_TRY(ft_conv1d_bwd_weight(g.g_h1, f, b.y1, d, g.g_c1_w, b.B, b.T, d, f, b.k1, b.T, b.T, ws, wsb, st));
+  FT_TRY(ft_linear_bwd_weight(g.d_sa, d, b.att, d, g.g_out_w, rows, d, d, 1, rows, 0, 0, 0, 0, ws, wsb, st));
+  FT_TRY(ft_linear_bwd_weight(g.dqkv, 3 * d, b.x, d, g.g_in_w, rows, d, 3 * d, 1, rows, 0, 0, 0, 0, ws, wsb, st));
+  return FT_OK;
+}
+
+// its bias and LayerNorm gradients: six column sums (twelve small launches) -- on a stream of their own, or they trail
+// behind the weight-gradient GEMMs at the end of the step (1.9 ms of a 15 ms FastPitch step, lab/steady_segments_fp.py)
+int block_bwd_sums(const FtFFTBlock& b, const FtFFTBlockGrads& g, void* ws, size_t wsb, void* st) {
   const int rows = b.B * b.T, d = b.d, f = b.dfft;
   FT_TRY(ft_colsum2(g.t2, g.dy2, d, g.g_n2_g, g.g_n2_b, rows, d, ws, wsb, st));
-  FT_TRY(ft_conv1d_bwd_weight(g.d_h2, d, b.h1, f, g.g_c2_w, b.B, b.T, f, d, b.k2, b.T, b.T, ws, wsb, st));
   FT_TRY(ft_colsum(g.d_h2, d, g.g_c2_b, rows, d, 1.0f, 0, ws, wsb, st));
-  FT_TRY(ft_conv1d_bwd_weight(g.g_h1, f, b.y1, d, g.g_c1_w, b.B, b.T, d, f, b.k1, b.T, b.T, ws, wsb, st));
   FT_TRY(ft_colsum(g.g_h1, f, g.g_c1_b, rows, f, 1.0f, 0, ws, wsb, st));
   FT_TRY(ft_colsum2(g.t1, g.d_y1, d, g.g_n1_g, g.g_n1_b, rows, d, ws, wsb, st));
-  FT_TRY(ft_linear_bwd_weight(g.d_sa, d, b.att, d, g.g_out_w, rows, d, d, 1, rows, 0, 0, 0, 0, ws, wsb, st));
   FT_TRY(ft_colsum(g.d_sa, d, g.g_out_b, rows, d, 1.0f, 0, ws, wsb, st));
-  FT_TRY(ft_linear_bwd_weight(g.dqkv, 3 * d, b.x, d, g.g_in_w, rows, d, 3 * d, 1, rows, 0, 0, 0, 0, ws, wsb, st));
   FT_TRY(ft_colsum(g.dqkv, 3 * d, g.g_in_b, rows, 3 * d, 1.0f, 0, ws, wsb, st));
   return FT_OK;
 }
@@ -101,29 +108,51 @@ size_t ft_fft_block_wgrad_workspace(int B, int T, int d, int dfft, int k1, int k
   up(ft_conv1d_bwd_weight_workspace(B, T, dfft, d, k2, T));
   up(ft_linear_bwd_weight_workspace(rows, d, d));
   up(ft_linear_bwd_weight_workspace(rows, d, 3 * d));
-  up(ft_colsum_workspace(rows, 3 * d));
+  return m;
+}
+
+size_t ft_fft_block_sums_workspace(int B, int T, int d, int dfft) {
+  const int rows = B * T;
+  size_t m = ft_colsum_workspace(rows, 3 * d);
+  auto up = [&](size_t v) { if (v > m) m = v; };
   up(ft_colsum_workspace(rows, dfft));
   up(2 * ft_colsum_workspace(rows, d));
   return m;
 }
 
 int ft_fft_blocks_bwd(const FtFFTBlock* blocks, const FtFFTBlockGrads* grads, int n, void* workspace,
-                      size_t workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, void* stream,
-                      void* wgrad_stream) {
+                      size_t workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, void* sums_workspace,
+                      size_t sums_workspace_bytes, void* stream, void* wgrad_stream, void* sums_stream) {
   FT_REQUIRE(blocks != nullptr && grads != nullptr && n >= 0, "fft_blocks_bwd: bad arguments");
-  const bool fork = wgrad_stream != nullptr && wgrad_stream != stream;
+  if (!wgrad_stream) wgrad_stream = stream;
+  if (!sums_stream) sums_stream = wgrad_stream;
+  FT_REQUIRE(sums_stream == wgrad_stream ? (sums_workspace == nullptr || sums_workspace == wgrad_workspace ||
+                                            (char*)sums_workspace >= (char*)wgrad_workspace + wgrad_workspace_bytes ||
+                                            (char*)sums_workspace + sums_workspace_bytes <= (char*)wgrad_workspace)
+                                         : sums_workspace != wgrad_workspace,
+             "fft_blocks_bwd: two streams must not share one workspace");
+  const bool fork = wgrad_stream != stream || sums_stream != stream;
   hipEvent_t ev = fork ? fork_event() : nullptr;
   FT_REQUIRE(!fork || ev != nullptr, "fft_blocks_bwd: could not create the fork event");
+  if (!sums_workspace) {
+    sums_workspace = wgrad_workspace;
+    sums_workspace_bytes = wgrad_workspace_bytes;
+    sums_stream = wgrad_stream;               // one workspace: one stream
+  }
   for (int i = n - 1; i >= 0; --i) {
     FT_TRY(block_bwd_data(blocks[i], grads[i], workspace, workspace_bytes, stream));
     if (fork) {
-      if (hipEventRecord(ev, (hipStream_t)stream) != hipSuccess ||
-          hipStreamWaitEvent((hipStream_t)wgrad_stream, ev, 0) != hipSuccess) {
+      bool ok = hipEventRecord(ev, (hipStream_t)stream) == hipSuccess;
+      if (wgrad_stream != stream) ok = ok && hipStreamWaitEvent((hipStream_t)wgrad_stream, ev, 0) == hipSuccess;
+      if (sums_stream != stream && sums_stream != wgrad_stream)
+        ok = ok && hipStreamWaitEvent((hipStream_t)sums_stream, ev, 0) == hipSuccess;
+      if (!ok) {
         ft_set_error("fft_blocks_bwd: stream fork failed");
         return FT_ERR_HIP;
       }
     }
-    FT_TRY(block_bwd_params(blocks[i], grads[i], wgrad_workspace, wgrad_workspace_bytes, fork ? wgrad_stream : stream));
+    FT_TRY(block_bwd_weights(blocks[i], grads[i], wgrad_workspace, wgrad_workspace_bytes, wgrad_stream));
+    FT_TRY(block_bwd_sums(blocks[i], grads[i], sums_workspace, sums_workspace_bytes, sums_stream));
   }
   return FT_OK;
 }

@@ -69,6 +69,10 @@ struct FtGemmBatch {
   //  hw_mode 2 (backward): the product (+ C when accumulate is set) is d(out) of the layer BELOW the one whose data
   //    gradient is being formed; the epilogue turns it into that layer's gate gradients at once:
   //    hw_d12 [M, 2 * hw_C] = d * g * (y1 > 0) | d * (relu(y1) - x) * g * (1 - g),  C = d * (1 - g)  (y1 | y2 = hw_x12).
+  // ReLU gradient mask in the epilogue (single-task / chained launches, identity output rows): C = (product) where
+  // relu_mask[row * ldc + col] > 0, else 0 -- the data gradient of a convolution that follows a conv + ReLU goes straight
+  // through that ReLU's derivative (FFTBlock conv2 -> conv1, common_layers.py:178-180), no element-wise pass in between
+  const float* relu_mask;
   int hw_mode, hw_C;
   const float* hw_x;
   const float* hw_b1;

@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void ft_gemm_rows_kernel(FtGemmBatch batch) {
         float v = acc[i][j][e] + bv;
         if (erelu) v = fmaxf(v, 0.f);
         if (escale) v = v * sc + sh;
+        if (batch.relu_mask && !(batch.relu_mask[crow * ldc + col] > 0.f)) v = 0.f;
         if (eacc) v += *cp;              // residual / gradient accumulation happens last
         *cp = v;
       }

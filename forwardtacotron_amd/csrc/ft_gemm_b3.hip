@@ -75,7 +75,8 @@ __device__ __forceinline__ void store_rn(unsigned short* row, const float4& v) {
 // layout as ft_gemm_rows_kernel.  `smem` = the (now idle) LDS tiles, >= 4 KB.
 template <int TM, int TN>
 __device__ __forceinline__ void rows_b3_epilogue(const FtGemmTask& T, float* TC, f32x16 (&acc)[TM][TN], unsigned short* smem,
-                                                 int m0, int n0, int tM, int tN, int tid, int mtile) {
+                                                 int m0, int n0, int tM, int tN, int tid, int mtile,
+                                                 const float* relu_mask = nullptr) {
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int half = lane >> 5, l31 = lane & 31;
@@ -123,6 +124,7 @@ __device__ __forceinline__ void rows_b3_epilogue(const FtGemmTask& T, float* TC,
           }
         }
         if (escale) v = v * sc + sh;
+        if (relu_mask && !(relu_mask[crow * ldc + col] > 0.f)) v = 0.f;
         if (eacc) v += *cp;
         *cp = v;
       }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3_kernel(FtGemmBatch bat
     ft_highway_epilogue<TM, TN>(batch, T, TC, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
     return;
   }
-  rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, blockIdx.x);
+  rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, blockIdx.x, batch.relu_mask);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     ft_highway_epilogue<TM, TN>(batch, T, TC, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
     return;
   }
-  rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, bx);
+  rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, bx, batch.relu_mask);
 }
 
 // ---------------------------------------------------------------------------------------------------

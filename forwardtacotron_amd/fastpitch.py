@@ -300,6 +300,18 @@ class _CGrads(_ct.Structure):
                                    'g_n1_g', 'g_n1_b', 'g_n2_g', 'g_n2_b')]
 
 
+_sums_streams = {}
+
+
+def _sums_stream(device) -> 'torch.cuda.Stream':
+    key = torch.device(device).index or 0
+    if key not in _sums_streams:
+        # high priority: twelve small kernels per block -- at default priority they only find free CUs once the other
+        # streams' one-wave GEMM grids have drained (the step's join then waited 5 ms for them)
+        _sums_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _sums_streams[key]
+
+
 _GRAD_FIELDS = ('g_in_w', 'g_in_b', 'g_out_w', 'g_out_b', 'g_c1_w', 'g_c1_b', 'g_c2_w', 'g_c2_b', 'g_n1_g', 'g_n1_b', 'g_n2_g',
                 'g_n2_b')
 _side_ws = {}
@@ -407,13 +419,27 @@ def blocks_bwd_composite(state, dy, params):
     ws = H.workspace(_lib.query('ft_attn_workspace', B, T, nhead), dev)
     side = sink.stream if (sink is not None and sink.stream is not None) else None
     side_raw = side.cuda_stream if side is not None else H._stream()
-    nb = _lib.query('ft_fft_block_wgrad_workspace', B, T, d, f, k1, k2)
-    key = (dev.index or 0, side_raw)
-    wws = _side_ws.get(key)
-    if wws is None or wws.numel() < nb:
-        wws = _side_ws[key] = torch.empty(max(nb, 1 << 20), dtype=torch.uint8, device=dev)
+    def side_buffer(raw, nbytes):
+        key = (dev.index or 0, raw)
+        buf = _side_ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = _side_ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        return buf
+
+    wws = side_buffer(side_raw, _lib.query('ft_fft_block_wgrad_workspace', B, T, d, f, k1, k2))
+    # FT_FFT_SUMS_STREAM=1: the blocks' bias / LayerNorm column sums on a stream of their own instead of behind the weight-
+    # gradient GEMMs, which finish 1.9 ms after the main stream (lab/steady_segments_fp.py).  Measured: 15.9 -> 17.3 ms per
+    # step, at default and at high priority alike -- 240 more small launches on a fourth stream cost more than the tail
+    # they remove (profiles/r03_fastpitch_ab.txt).  Off.
+    sums = _sums_stream(dev) if side is not None and os.environ.get('FT_FFT_SUMS_STREAM', '0') == '1' else None
+    sums_raw = sums.cuda_stream if sums is not None else None
+    sws = side_buffer(('sums', sums_raw), _lib.query('ft_fft_block_sums_workspace', B, T, d, f)) if sums is not None else None
     _lib.call('ft_fft_blocks_bwd', _ct.byref(blocks), _ct.byref(grads), n, ws.data_ptr(), ws.numel(), wws.data_ptr(),
-              wws.numel(), H._stream(), side_raw)
+              wws.numel(), _p(sws), sws.numel() if sws is not None else 0, H._stream(), side_raw, sums_raw)
+    if sums is not None:
+        sink.used.add(sums)
+        if sink.reducer_streams is not None:
+            sink.reducer_streams.add(sums)
     dx = last_dh[0][last_dh[1]:last_dh[1] + R * d].view(B, T, d)     # d wrt the first block's input, in place
     if sink is None:
         dx._ft_keep = (scratch, state['arenas'], state['keep'])       # no sink: everything ran on this stream, in order

@@ -63,6 +63,9 @@ class GradSink:
         # gradients; one of the four rebalances the two.
         self.late_ok = False
         self.late = []
+        # set by the trainer: the set of streams a gradient bucket's all-reduce waits for; whoever writes gradients on yet
+        # another stream adds it here
+        self.reducer_streams = None
 
     def begin_step(self):
         self.written.clear()

@@ -85,6 +85,7 @@ class TrainStep:
         self.sink = ops.GradSink({p.data_ptr(): (i, p.grad) for i, p in enumerate(self.flat.params)},
                                  stream=self.wgrad_stream, on_write=self.reducer.notify)
         self.reducer.held = self.sink.held
+        self.sink.reducer_streams = self.reducer.streams     # streams a bucket's all-reduce must wait for
         self.packs: Optional[H.PackCache] = None
         self.main_stream = (torch.cuda.Stream(device=dev, priority=-1)
                             if os.environ.get('FT_MAIN_PRIORITY', '1') == '1' else None)

@@ -101,6 +101,11 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
 /* dx[b,t,ci] (+)= sum_j sum_co dy[b, t-j+k/2, co] * w[co,ci,j]; dy is [B,Tbuf,*] of which rows < Tvalid count */
 int ft_conv1d_bwd_data(const float* dy, long lddy, const float* wp, float* dx, long lddx, int B, int T, int Cin,
                        int Cout, int k, int Tbuf, int Tvalid, int accumulate, int wp_transposed, void* stream);
+/* the same through a ReLU's derivative: dx[r,c] = (that product) if y[r*lddx + c] > 0 else 0, y = the OUTPUT of the conv + ReLU
+ * whose result this convolution consumed (FFTBlock: conv2's data gradient is conv1's pre-ReLU gradient,
+ * common_layers.py:178-180) -- the mask is the GEMM's epilogue, not an element-wise pass.  T = Tbuf = Tvalid. */
+int ft_conv1d_bwd_data_relu(const float* dy, long lddy, const float* wp, const float* y, float* dx, long lddx, int B,
+                            int T, int Cin, int Cout, int k, int wp_transposed, void* stream);
 /* dx (+)= sum_i dy_i[rows,out_f] * w_i[out_f,in_f]: the data gradients of several nn.Linear that read the same input
  * (HighwayNetwork W1/W2, common_layers.py:35-40; the two directions' W_ih of nn.GRU / nn.LSTM) in ONE launch,
  * accumulated in registers.  dy / w: host arrays of ntasks device pointers (ntasks <= 16). */
@@ -462,11 +467,14 @@ typedef struct FtFFTBlockGrads {
 } FtFFTBlockGrads;
 int ft_fft_blocks_fwd(const FtFFTBlock* blocks, int n, void* stream);
 /* workspace: >= ft_attn_workspace(B,T,nheads) bytes (main stream); wgrad_workspace: >= ft_fft_block_wgrad_workspace(...)
- * bytes (used on wgrad_stream only).  wgrad_stream may equal stream. */
+ * bytes, used on wgrad_stream only (the four weight-gradient GEMMs of a block); sums_workspace: >=
+ * ft_fft_block_sums_workspace(...) bytes, used on sums_stream only (its bias / LayerNorm column sums).  wgrad_stream /
+ * sums_stream NULL = stream / wgrad_stream; sums_workspace NULL = the sums share wgrad_stream and its workspace. */
 size_t ft_fft_block_wgrad_workspace(int B, int T, int d, int dfft, int k1, int k2);
+size_t ft_fft_block_sums_workspace(int B, int T, int d, int dfft);
 int ft_fft_blocks_bwd(const FtFFTBlock* blocks, const FtFFTBlockGrads* grads, int n, void* workspace,
-                      size_t workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, void* stream,
-                      void* wgrad_stream);
+                      size_t workspace_bytes, void* wgrad_workspace, size_t wgrad_workspace_bytes, void* sums_workspace,
+                      size_t sums_workspace_bytes, void* stream, void* wgrad_stream, void* sums_stream);
 
 /* ---- mel inversion + Griffin-Lim (utils/dsp.py:80-94 DSP.griffinlim ; gen_forward.py:109-116) ------------ */
 /* The DFTs are GEMMs on ft_linear_fwd (frames read in place out of the zero-padded signal with ldx = hop); these are

@@ -1,8 +1,9 @@
 #!/bin/bash
 # One gpurun call: bench line, kernel-trace stats, three PMC passes (SQ MFMA counters, FETCH_SIZE, WRITE_SIZE).
-# usage (from the repo root on the GPU box): bash tools/gpu_profile_r02.sh <tag>
-set -e
-TAG=${1:-r02a}
+# usage (from the repo root on the GPU box): bash tools/gpu_profile_r03.sh <tag>
+# (no `set -e`: rocprofv3 has been seen to crash in a static destructor AFTER it has written its output -- the files are
+# complete, the exit code is not 0)
+TAG=${1:-r03a}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -24,6 +25,8 @@ python tools/pmc_report.py $OUT > $OUT/pmc_report.txt 2>&1 || true
 T=$(ls $OUT/trace/*/*kernel_trace.csv | head -1)
 python profiles/summarize.py $T 60 > $OUT/last_step_summary.txt 2>&1 || true
 python tools/trace_gaps.py $T >> $OUT/last_step_summary.txt 2>&1 || true
+python tools/stream_timeline.py $T > $OUT/timeline_main.txt 2>&1 || true
+python lab/steady_segments.py > $OUT/steady_segments.txt 2>&1 || true
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv || true
 find $OUT -name '*counter_collection.csv' -size +20M -delete
 find $OUT -name '*kernel_trace.csv' -size +20M -delete
