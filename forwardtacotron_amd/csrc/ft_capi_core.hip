@@ -30,8 +30,8 @@ int ft_check_launch(const char* what) {
 }
 
 int ft_lr_scan_impl(float*, int, int, int*, int*, hipStream_t);
-int ft_lr_expand_impl(const float*, const int*, float*, int*, int, int, int, int, hipStream_t);
-int ft_lr_bwd_impl(const float*, const int*, float*, int, int, int, int, hipStream_t);
+int ft_lr_expand_impl(const float*, const int*, float*, int*, int, int, int, int, hipStream_t, int = 0, const float* = nullptr);
+int ft_lr_bwd_impl(const float*, const int*, float*, int, int, int, int, hipStream_t, int = 0, float* = nullptr);
 
 // ft_bn.hip: statistics partials by the stand-alone column pass (C++ linkage), and the partial-buffer size query
 int ft_bn_stat_partials(const float* y, int B, int Tbuf, int C, int group, double* partial, hipStream_t s);
@@ -131,13 +131,38 @@ int ft_linear_fwd(const float* x, long ldx, const float* w, const float* bias, f
   return ft_launch_gemm_rows(&b, 1, false, (hipStream_t)stream);
 }
 
+static int linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
+                            float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
+                            int x_tm_B, int y_tm_B, long as_rows, void* stream);
+
 int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
                         float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
                         int x_tm_B, int y_tm_B, void* stream) {
+  return linear_multi_fwd(x, ldx, ntasks, w, bias, y, ldy, col_offset, out_f, rows, in_f, relu, x_tm_B, y_tm_B, 0, stream);
+}
+int ft_linear_multi_fwd_as(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
+                           float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, long as_rows,
+                           void* stream) {
+  FT_REQUIRE(as_rows >= 1, "linear_multi_fwd_as: as_rows (%ld) must be positive", as_rows);
+  return linear_multi_fwd(x, ldx, ntasks, w, bias, y, ldy, col_offset, out_f, rows, in_f, 0, 0, 0, as_rows, stream);
+}
+
+static int linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
+                            float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
+                            int x_tm_B, int y_tm_B, long as_rows, void* stream) {
   FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_multi_fwd: ntasks %d out of range", ntasks);
   if (check_tm("linear_multi_fwd", rows, x_tm_B) || check_tm("linear_multi_fwd", rows, y_tm_B)) return FT_ERR_ARG;
   FtGemmBatch b;
   memset(&b, 0, sizeof(b));
+  if (as_rows > 0) {      // the tile (= the kernel, = the rounding) a launch over as_rows rows of the same layers takes
+    long tiles = 0;
+    int maxN = 0;
+    for (int i = 0; i < ntasks; ++i) {
+      tiles += (long)ft_cdiv(as_rows, 128) * ft_cdiv(out_f[i], 128);
+      if (out_f[i] > maxN) maxN = out_f[i];
+    }
+    b.force_tile = ft_rows_tile_is_big(tiles, as_rows > 0x7fffffffL ? 0x7fffffff : (int)as_rows, maxN) ? 2 : 1;
+  }
   for (int i = 0; i < ntasks; ++i) {
     FtGemmTask& t = b.t[i];
     t.A = x; t.B = w[i]; t.C = y + col_offset[i]; t.bias = bias ? bias[i] : nullptr;
@@ -662,6 +687,13 @@ int ft_lr_expand(const float* x, const int* cum, float* y, int* src_idx, int B, 
 }
 int ft_lr_bwd(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, void* stream) {
   return ft_lr_bwd_impl(dy, cum, dx, B, Tx, Tm, C, (hipStream_t)stream);
+}
+int ft_lr_expand_tm(const float* x, const int* cum, const float* pad_row, float* y, int B, int Tx, int Tm, int C,
+                    void* stream) {
+  return ft_lr_expand_impl(x, cum, y, nullptr, B, Tx, Tm, C, (hipStream_t)stream, 1, pad_row);
+}
+int ft_lr_bwd_tm(const float* dy, const int* cum, float* dx, float* dtail, int B, int Tx, int Tm, int C, void* stream) {
+  return ft_lr_bwd_impl(dy, cum, dx, B, Tx, Tm, C, (hipStream_t)stream, 1, dtail);
 }
 
 }  // extern "C"

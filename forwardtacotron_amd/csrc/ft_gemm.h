@@ -73,6 +73,10 @@ struct FtGemmBatch {
   // relu_mask[row * ldc + col] > 0, else 0 -- the data gradient of a convolution that follows a conv + ReLU goes straight
   // through that ReLU's derivative (FFTBlock conv2 -> conv1, common_layers.py:178-180), no element-wise pass in between
   const float* relu_mask;
+  // force_tile: 0 = the launcher picks the tile (and with it the kernel: 128x128 bf16-split or 64x64 f32) from the
+  // launch's own size; 1 = 64, 2 = 128 -- a GEMM issued in row chunks then rounds exactly like the same GEMM issued
+  // whole (ft_*_layer_fwd; ft_rows_tile_is_big gives the whole launch's choice)
+  int force_tile;
   int hw_mode, hw_C;
   const float* hw_x;
   const float* hw_b1;
@@ -232,6 +236,9 @@ __device__ __forceinline__ FtTnWho ft_tn_who(const FtGemmTNTask& T, int S, int B
   return w;
 }
 
+// the launcher's tile choice for a launch whose tasks have `tiles128` 128x128 output tiles in total
+static inline bool ft_rows_tile_is_big(long tiles128, int maxM, int maxN) { return tiles128 >= 192 && maxN > 64 && maxM > 64; }
+static_assert(sizeof(FtGemmBatch) <= 4080, "FtGemmBatch travels as a kernel argument (4 KB limit)");
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream);
 // fp32 on the bf16 matrix pipe (exact 3-way operand split, ft_gemm_b3.hip); NT + FAST launches, FT_GEMM_B3=0 disables
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream);

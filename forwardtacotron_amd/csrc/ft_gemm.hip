@@ -666,7 +666,7 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   } else {
     batch->chain = 0;
   }
-  const bool big = tiles128 >= 192 && maxN > 64 && maxM > 64;
+  const bool big = batch->force_tile ? batch->force_tile == 2 : ft_rows_tile_is_big(tiles128, maxM, maxN);
   const int bm = big ? 128 : 64;
   dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), chained ? 1 : (ntasks == 1 ? batch->t[0].nz : ntasks));
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_rows: grid too large");

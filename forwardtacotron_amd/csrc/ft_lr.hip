@@ -41,10 +41,13 @@ __global__ __launch_bounds__(64) void ft_lr_scan_kernel(float* dur, int Tx, int*
 }
 
 // one block = FR frames of one item; each wave copies FR/4 rows
+// output row of (b, t) = b * y_bs + t * y_ts (batch-major: Tm, 1; time-major: 1, B); pad_row (optional, C floats) is
+// what rows beyond an item's frames hold instead of zeros
 template <int FR>
 __global__ __launch_bounds__(256) void ft_lr_expand_kernel(const float* __restrict__ x, const int* __restrict__ cum,
                                                            float* __restrict__ y, int* __restrict__ src_idx,
-                                                           int Tx, int Tm, int C, int vec) {
+                                                           int Tx, int Tm, int C, int vec, long y_bs, long y_ts,
+                                                           const float* __restrict__ pad_row) {
   __shared__ int src[FR];
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * FR;
@@ -69,16 +72,42 @@ __global__ __launch_bounds__(256) void ft_lr_expand_kernel(const float* __restri
     int t = t0 + f;
     if (t >= Tm) break;
     int tok = src[f];
-    float* yr = y + ((long)b * Tm + t) * C;
+    float* yr = y + ((long)b * y_bs + (long)t * y_ts) * C;
     if (vec) {
-      const float4* xr = reinterpret_cast<const float4*>(x + ((long)b * Tx + (tok < 0 ? 0 : tok)) * C);
+      const float4* xr = reinterpret_cast<const float4*>(tok < 0 ? pad_row : x + ((long)b * Tx + tok) * C);
       float4* y4 = reinterpret_cast<float4*>(yr);
-      for (int i = lane; i < C / 4; i += 64) y4[i] = tok < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : xr[i];
+      for (int i = lane; i < C / 4; i += 64) y4[i] = xr ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      const float* xr = x + ((long)b * Tx + (tok < 0 ? 0 : tok)) * C;
-      for (int i = lane; i < C; i += 64) yr[i] = tok < 0 ? 0.f : xr[i];
+      const float* xr = tok < 0 ? pad_row : x + ((long)b * Tx + tok) * C;
+      for (int i = lane; i < C; i += 64) yr[i] = xr ? xr[i] : 0.f;
     }
   }
+}
+
+// one wave per (token row, 256-column chunk): a lane adds the frames' float4 of its 4 columns, in frame order.  dy row of
+// (b, t) = b * dy_bs + t * dy_ts (as in the expand kernel)
+// dtail (optional, [B,C]): rows B*Tx .. B*Tx+B-1 of the grid add up the frames BEYOND item b's tokens (t >= cum[b][Tx]) --
+// they belong to no token, but a column sum over all frames (a bias gradient) needs them
+__global__ __launch_bounds__(256) void ft_lr_bwd_cols_kernel(const float* __restrict__ dy, const int* __restrict__ cum,
+                                                             float* __restrict__ dx, float* __restrict__ dtail, int B,
+                                                             int Tx, int Tm, int C, long dy_bs, long dy_ts) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + wave;
+  const int col = (blockIdx.y * 64 + lane) * 4;
+  const long ntok = (long)B * Tx;
+  if (row >= ntok + (dtail ? B : 0) || col >= C) return;
+  const bool tail = row >= ntok;
+  const int b = tail ? (int)(row - ntok) : (int)(row / Tx), j = tail ? Tx : (int)(row - (long)b * Tx);
+  const int* c = cum + (long)b * (Tx + 1);
+  int f0 = c[j], f1 = tail ? Tm : c[j + 1];
+  if (f1 > Tm) f1 = Tm;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* src = dy + ((long)b * dy_bs + (long)f0 * dy_ts) * C + col;
+  for (int t = f0; t < f1; ++t, src += dy_ts * C) {
+    const float4 g = *reinterpret_cast<const float4*>(src);
+    a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+  }
+  *reinterpret_cast<float4*>((tail ? dtail + (long)b * C : dx + row * C) + col) = a;
 }
 
 // one wave per token row
@@ -120,21 +149,29 @@ int ft_lr_scan_impl(float* dur, int B, int Tx, int* cum, int* total, hipStream_t
 }
 
 int ft_lr_expand_impl(const float* x, const int* cum, float* y, int* src_idx, int B, int Tx, int Tm, int C,
-                      hipStream_t stream) {
+                      hipStream_t stream, int y_time_major, const float* pad_row) {
   FT_REQUIRE(B >= 0 && Tx >= 0 && Tm >= 0 && C >= 0, "lr_expand: bad dims");
   if (B == 0 || Tm == 0 || C == 0) return FT_OK;
   FT_REQUIRE(Tx > 0, "lr_expand: Tm > 0 requires Tx > 0");
-  int vec = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+  int vec = (C % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)pad_row % 16 == 0);
   constexpr int FR = 16;
   hipLaunchKernelGGL(ft_lr_expand_kernel<FR>, dim3(ft_cdiv(Tm, FR), B), dim3(256), 0, stream, x, cum, y, src_idx,
-                     Tx, Tm, C, vec);
+                     Tx, Tm, C, vec, y_time_major ? 1L : (long)Tm, y_time_major ? (long)B : 1L, pad_row);
   return ft_check_launch("lr_expand");
 }
 
-int ft_lr_bwd_impl(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, hipStream_t stream) {
+int ft_lr_bwd_impl(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, hipStream_t stream,
+                   int dy_time_major, float* dtail) {
   FT_REQUIRE(B >= 0 && Tx >= 0 && Tm >= 0 && C >= 0, "lr_bwd: bad dims");
   if (B == 0 || Tx == 0 || C == 0) return FT_OK;
   int vec = (C % 4 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0);
+  if (dy_time_major || dtail || (vec && C >= 1024)) {      // wide rows: one wave per 256 columns instead of per row
+    FT_REQUIRE(vec && (uintptr_t)dtail % 16 == 0, "lr_bwd: this form needs C %% 4 == 0 and 16-byte aligned buffers");
+    hipLaunchKernelGGL(ft_lr_bwd_cols_kernel, dim3(ft_cdiv((long)B * Tx + (dtail ? B : 0), 4), ft_cdiv(C, 256)), dim3(256),
+                       0, stream, dy, cum, dx, dtail, B, Tx, Tm, C, dy_time_major ? 1L : (long)Tm,
+                       dy_time_major ? (long)B : 1L);
+    return ft_check_launch("lr_bwd");
+  }
   hipLaunchKernelGGL(ft_lr_bwd_kernel, dim3(ft_cdiv((long)B * Tx, 4)), dim3(256), 0, stream, dy, cum, dx, B, Tx, Tm,
                      C, vec);
   return ft_check_launch("lr_bwd");

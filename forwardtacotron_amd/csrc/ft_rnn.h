@@ -18,6 +18,14 @@ struct RnnFwdArgs {
   // rows per time step of the buffers (the persistent forward can be launched on a SLICE of the batch: B rows starting
   // at the pointers above, inside buffers whose time steps are Bld rows apart); the per-step kernels take Bld == B
   int Bld;
+  // input gate (persistent forward only; null = off): the x projection arrives in TIME CHUNKS of gate_cs steps while the
+  // recurrence already runs -- direction 0 in ascending t, direction 1 in descending t (chunk j of direction 1 covers
+  // t in [T - (j+1)*gate_cs, T - j*gate_cs)).  gate[d] = index of the last chunk of direction d whose rows are complete
+  // in memory (chunk 0 is complete at launch; the word is raised by ft_gate_set_kernel launches behind the chunks'
+  // GEMMs on another stream).  A cell thread polls it (bounded, like every spin here) before it requests a row of a
+  // chunk it has not seen complete, and reads xp past L1.
+  const unsigned* gate;
+  int gate_cs;
 };
 
 struct RnnBwdArgs {
@@ -59,4 +67,6 @@ __device__ __forceinline__ int clamp_len(const long* lens, int b, int T) {
 // One-launch persistent recurrences (ft_rnn_persist.hip).  Return FT_OK if launched, -1 if the persistent form does
 // not apply (the caller then issues the per-step kernels).
 int ft_rnn_fwd_persistent(int G, RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream);
+// share of one XCD's CUs the persistent forward of this shape would hold (-1: it would not run persistent)
+double ft_rnn_fwd_xcd_fill(int G, int B, int T, int H, void* ws, size_t ws_bytes);
 int ft_rnn_bwd_persistent(int G, RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -26,6 +26,9 @@
 //   backward pass: t = L_b-1-s (dir 0) | s (dir 1) ;  "next" (already done) t+1|t-1 ; h_prev at t-1 | t+1
 #include <stdlib.h>
 
+#include <string.h>
+
+#include "ft_gemm.h"
 #include "ft_rnn.h"
 
 namespace {
@@ -325,16 +328,24 @@ void launch_fwd(bool fast, dim3 grid, hipStream_t stream, const RnnFwdArgs& a) {
 template <int G>
 int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
             float* out, float* cst, float* gates, const long* lens, int B, int T, int H, void* ws,
-            size_t ws_bytes, hipStream_t stream) {
+            size_t ws_bytes, hipStream_t stream, const unsigned* gate = nullptr, int gate_cs = 0,
+            hipEvent_t xp_complete = nullptr) {
   RnnFwdArgs a;
   a.xp = xp; a.whh[0] = whh_f; a.whh[1] = whh_r; a.bhh[0] = bhh_f; a.bhh[1] = bhh_r;
   a.out = out; a.cst = cst; a.gates = gates; a.lens = lens;
   a.B = B; a.T = T; a.H = H; a.ND = 2; a.Bld = B;
+  a.gate = gate; a.gate_cs = gate_cs;
   a.vec = (H % 4 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)whh_f % 16 == 0) && ((uintptr_t)whh_r % 16 == 0);
   const bool fast = a.vec && (H % 16 == 0);
   {
     const int rc = ft_rnn_fwd_persistent(G, a, ws, ws_bytes, stream);      // writes the zeros of finished items itself
     if (rc != -1) return rc;
+  }
+  // only the single persistent launch reads xp chunk by chunk: every other form waits for all of it
+  if (gate) {
+    if (xp_complete) (void)hipStreamWaitEvent(stream, xp_complete, 0);
+    a.gate = nullptr;
+    a.gate_cs = 0;
   }
   // A batch too large for ONE persistent grid (all workgroups must be co-resident: the 512-wide LSTM fills the chip at 64
   // rows) runs as several persistent launches over 64-row slices of the batch, one after the other -- batch rows are
@@ -421,9 +432,127 @@ int rnn_bwd(const float* dout, const float* out, const float* cst, const float* 
   return ft_check_launch("rnn_bwd");
 }
 
+#define FT_HIP_OK(call)                                   \
+  do {                                                    \
+    if ((call) != hipSuccess) {                           \
+      ft_set_error("rnn layer: %s failed", #call);        \
+      return FT_ERR_HIP;                                  \
+    }                                                     \
+  } while (0)
+
+__global__ void ft_gate_set_kernel(unsigned* word, unsigned value) {
+  __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipEvent_t layer_event(int which) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  static hipEvent_t ev[16][2] = {};
+  if (dev < 0 || dev >= 16) return nullptr;
+  hipEvent_t& e = ev[dev][which];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+  return e;
+}
+
+// A recurrent LAYER's forward with the input projection overlapped with the recurrence: x * W_ih^T + b_ih is formed in
+// time chunks -- chunk 0 of both directions on `stream`, the others on `side` -- and the persistent recurrence, launched
+// right behind chunk 0, takes each chunk when its gate word says it is complete (RnnFwdArgs.gate).  The recurrence
+// leaves most of the chip idle (it is bound by the cross-CU hand-off, not by work), which is where the rest of the
+// projection GEMM now runs instead of in front of it.  x is batch-major [B,T,In]; xp time-major [T,B,2*G*H].
+// rev_lead: chunks of direction 1 issued before the alternation starts (a packed item of length L_b starts at
+// t = L_b - 1, i.e. inside chunk (T - L_b) / cs of that direction, so its group waits for that many chunks at once).
+template <int G>
+int rnn_layer_fwd(const float* x, int In, const float* const* wih, const float* const* bih, float* xp,
+                  const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r, const long* lens,
+                  float* out, float* cst, float* gates, int B, int T, int H, void* ws, size_t ws_bytes, unsigned* gate,
+                  int nchunks, int rev_lead, hipStream_t stream, hipStream_t side) {
+  const long ldy = 2L * G * H;
+  auto project = [&](int d, int t0, int n, hipStream_t st) {
+    FtGemmBatch b;
+    memset(&b, 0, sizeof(b));
+    FtGemmTask& t = b.t[0];
+    t.A = x + (long)t0 * In; t.B = wih[d]; t.C = xp + (long)t0 * B * ldy + (long)d * G * H; t.bias = bih ? bih[d] : nullptr;
+    t.lda = In; t.ldb = In; t.ldc = ldy;
+    t.M = B * n; t.N = G * H; t.K = In; t.taps = 1;
+    t.amap = FtRowMap{n, T, 1, n, 0, 0};            // rows (b, t0 + t) of the batch-major input
+    t.cmap = FtRowMap{n, 1, B, n, 0, 0};            // time-major output
+    // the same kernel as ft_linear_multi_fwd's two-task launch over all B * T rows takes: bit-identical results
+    b.force_tile = ft_rows_tile_is_big(2L * ft_cdiv((long)B * T, 128) * ft_cdiv(G * H, 128), B * T, G * H) ? 2 : 1;
+    return ft_launch_gemm_rows(&b, 1, false, st);
+  };
+  int cs = nchunks > 1 ? (T + nchunks - 1) / nchunks : T;
+  if (cs < 16) cs = 16;
+  const int nc = T > 0 ? (T + cs - 1) / cs : 1;
+  hipEvent_t ev0 = layer_event(0), ev1 = layer_event(1);
+  // a recurrence that fills whole XCDs (the 512-wide LSTM) stops the dispatch of every other kernel while it is resident:
+  // chunks launched beside it would only run after it -- and it would wait for them (ft_rnn_fwd_xcd_fill)
+  const double fill = (nc >= 2 && side && gate) ? ft_rnn_fwd_xcd_fill(G, B, T, H, ws, ws_bytes) : -1.0;
+  if (nc < 2 || !side || side == stream || !gate || !ev0 || !ev1 || fill < 0.0 || fill > 0.75) {
+    int rc = project(0, 0, T, stream);
+    if (rc == FT_OK) rc = project(1, 0, T, stream);
+    if (rc != FT_OK) return rc;
+    return rnn_fwd<G>(xp, whh_f, whh_r, bhh_f, bhh_r, out, cst, gates, lens, B, T, H, ws, ws_bytes, stream);
+  }
+  auto chunk = [&](int d, int j, hipStream_t st) {
+    const int lo = d == 0 ? j * cs : (T - (j + 1) * cs > 0 ? T - (j + 1) * cs : 0);
+    const int hi = d == 0 ? (lo + cs < T ? lo + cs : T) : T - j * cs;
+    return project(d, lo, hi - lo, st);
+  };
+  (void)hipMemsetAsync(gate, 0, 2 * sizeof(unsigned), stream);
+  int rc = chunk(0, 0, stream);
+  if (rc == FT_OK) rc = chunk(1, 0, stream);
+  if (rc != FT_OK) return rc;
+  FT_HIP_OK(hipEventRecord(ev0, stream));
+  FT_HIP_OK(hipStreamWaitEvent(side, ev0, 0));
+  int next[2] = {1, 1};
+  auto issue = [&](int d) {
+    if (next[d] >= nc || rc != FT_OK) return;
+    rc = chunk(d, next[d], side);
+    hipLaunchKernelGGL(ft_gate_set_kernel, dim3(1), dim3(1), 0, side, gate + d, (unsigned)next[d]);
+    ++next[d];
+  };
+  for (int i = 0; i < rev_lead; ++i) issue(1);
+  while ((next[0] < nc || next[1] < nc) && rc == FT_OK) {
+    issue(0);
+    issue(1);
+  }
+  FT_HIP_OK(hipEventRecord(ev1, side));
+  if (rc != FT_OK) {
+    (void)hipStreamWaitEvent(stream, ev1, 0);
+    return rc;
+  }
+  rc = rnn_fwd<G>(xp, whh_f, whh_r, bhh_f, bhh_r, out, cst, gates, lens, B, T, H, ws, ws_bytes, stream, gate, cs, ev1);
+  (void)hipStreamWaitEvent(stream, ev1, 0);         // (already passed: the recurrence consumed every chunk)
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ft_lstm_layer_fwd(const float* x, int in_f, const float* wih_f, const float* wih_r, const float* bih_f,
+                      const float* bih_r, float* xp, const float* whh_f, const float* whh_r, const float* bhh_f,
+                      const float* bhh_r, const long* lens, float* out_raw, float* cstate, float* gates, int B, int T,
+                      int H, void* workspace, size_t workspace_bytes, unsigned* gate, int nchunks, int rev_lead,
+                      void* stream, void* side_stream) {
+  FT_REQUIRE(B > 0 && T >= 0 && H > 0 && in_f > 0, "lstm_layer_fwd: bad dims");
+  const float* wih[2] = {wih_f, wih_r};
+  const float* bih[2] = {bih_f, bih_r};
+  return rnn_layer_fwd<4>(x, in_f, wih, bih, xp, whh_f, whh_r, bhh_f, bhh_r, lens, out_raw, cstate, gates, B, T, H,
+                          workspace, workspace_bytes, gate, nchunks, rev_lead, (hipStream_t)stream,
+                          (hipStream_t)side_stream);
+}
+
+int ft_gru_layer_fwd(const float* x, int in_f, const float* wih_f, const float* wih_r, const float* bih_f,
+                     const float* bih_r, float* xp, const float* whh_f, const float* whh_r, const float* bhh_f,
+                     const float* bhh_r, float* out, float* gates, int B, int T, int H, void* workspace,
+                     size_t workspace_bytes, unsigned* gate, int nchunks, void* stream, void* side_stream) {
+  FT_REQUIRE(B > 0 && T >= 0 && H > 0 && in_f > 0, "gru_layer_fwd: bad dims");
+  const float* wih[2] = {wih_f, wih_r};
+  const float* bih[2] = {bih_f, bih_r};
+  return rnn_layer_fwd<3>(x, in_f, wih, bih, xp, whh_f, whh_r, bhh_f, bhh_r, nullptr, out, nullptr, gates, B, T, H,
+                          workspace, workspace_bytes, gate, nchunks, 0, (hipStream_t)stream, (hipStream_t)side_stream);
+}
 
 int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
                float* out, float* gates, int B, int T, int H, void* workspace, size_t workspace_bytes,

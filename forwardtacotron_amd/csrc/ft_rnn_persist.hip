@@ -40,6 +40,7 @@
 //     lines and the 128-B lines of out / gates / xp rows are shared inside one or two L2s instead of all eight.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <vector>
@@ -353,16 +354,61 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
   float xg[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) xg[g] = 0.f;
-  if (cthr && 0 < L) {
-    const int ct = d == 0 ? 0 : L - 1;
-    const float* xr = a.xp + ((long)ct * a.Bld + cb) * ldx + (long)d * G * H + cun;
-#pragma unroll
-    for (int g = 0; g < G; ++g) xg[g] = xr[(long)g * H];
+  // Gated launches (RnnFwdArgs.gate): the x projection arrives in time chunks while this kernel runs.  ONE thread of the
+  // workgroup keeps ahead of the cell threads' requests: at the top of step s it makes sure the chunk that holds the
+  // rows of step s + 2 (requested during step s + 1, behind this step's barrier) is complete, polling the direction's
+  // gate word if it has not seen it that far yet -- one sc1 load every few microseconds per workgroup (a first version
+  // in which every cell thread polled kept 500 waves hammering one memory channel: the chunk GEMM they were waiting for
+  // did not finish).  Direction 1 of a packed batch: item b starts at t = L_b - 1, i.e. (T - L_b) rows into the
+  // direction's descending chunk order; the workgroup takes the deepest of its 16 rows.  The values are read past L1
+  // (another kernel wrote them while this one runs).
+  const bool gated = a.gate != nullptr;
+  int gate_off = 0;
+  unsigned gate_have = 1u;              // chunks of this direction seen complete (thread 0)
+  if (gated && d == 1) {
+    int lm = T;
+    for (int i = 0; i < MB; ++i)
+      if (b0 + i < a.B) lm = min(lm, clamp_len(a.lens, b0 + i, T));
+    gate_off = T - lm;
   }
+  auto gate_ahead = [&](int step) {     // thread 0: the rows the workgroup requests for `step` are complete
+    const int pos = min(gate_off + step, T - 1);
+    const unsigned need = (unsigned)pos / (unsigned)a.gate_cs;
+    if (need >= gate_have) {
+      bool ok = geo.max_spins != 0;       // 0 = fault injection
+      unsigned spins = 0;
+      while (ok && (gate_have = 1u + __hip_atomic_load(a.gate + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= need) {
+        __builtin_amdgcn_s_sleep(127);
+        if (++spins > geo.max_spins) ok = false;
+      }
+      if (!ok) s_fail = 1;
+    }
+  };
+  if (gated) {
+    __syncthreads();                    // s_fail is initialised
+    if (tid == 0) {
+      gate_ahead(0);
+      gate_ahead(1);
+    }
+    __syncthreads();
+  }
+  auto xload = [&](int cn, float (&dst)[G]) {
+    const float* xr = a.xp + ((long)cn * a.Bld + cb) * ldx + (long)d * G * H + cun;
+    if (gated) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        dst[g] = __hip_atomic_load(xr + (long)g * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) dst[g] = xr[(long)g * H];
+    }
+  };
+  if (cthr && 0 < L) xload(d == 0 ? 0 : L - 1, xg);
 
   PROF_DECL;
   for (int s = 0; s < T; ++s) {
     PROF(0);
+    if (gated && tid == 0) gate_ahead(s + 2);
     const bool cact = cthr && s < L;
     const int ct = d == 0 ? s : L - 1 - s;
     float* red = red2 + (s & 1) * (NW * NT * 16 * RLD);
@@ -379,12 +425,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
 #pragma unroll
     for (int g = 0; g < G; ++g) xn[g] = 0.f;
     auto request_xn = [&]() {
-      if (cthr && s + 1 < L) {
-        const int cn = d == 0 ? s + 1 : L - 2 - s;
-        const float* xr = a.xp + ((long)cn * a.Bld + cb) * ldx + (long)d * G * H + cun;
-#pragma unroll
-        for (int g = 0; g < G; ++g) xn[g] = xr[(long)g * H];
-      }
+      if (cthr && s + 1 < L) xload(d == 0 ? s + 1 : L - 2 - s, xn);
     };
     const bool gl = local;              // protocol of THIS step's operands (the mode may change below, at s == 1)
     // granule mode of this step (wave-uniform): XCD-local, bf16-split (file header).  Block c+1 is requested before
@@ -1452,8 +1493,16 @@ double plan_launch(KernelT kernel, int block, Geom& geo, int& grid, hipStream_t 
   return -1.0;
 }
 
+// fill_probe (ft_rnn_fwd_xcd_fill): no launch -- report the share of an XCD's CUs the aligned layout of this kernel holds
+double* g_fill_probe = nullptr;
+
 template <int G, int NW, bool B3, int UB, int BC>
 int launch_fwd_persist(const RnnFwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
+  if (g_fill_probe) {
+    const int ngroups = geo.total / geo.nchunks;
+    *g_fill_probe = xcd_demand(ft_rnn_fwd_persist_kernel<G, NW, B3, UB, BC>, NW * 64, geo.nchunks * ft_cdiv(ngroups, 8));
+    return FT_OK;
+  }
   int grid = 0;
   const double cus = plan_launch(ft_rnn_fwd_persist_kernel<G, NW, B3, UB, BC>, NW * 64, geo, grid, stream);
   if (cus < 0.0) return -1;
@@ -1620,6 +1669,23 @@ unsigned* ft_rnn_fault_word() {
     cache[dev] = (unsigned*)p;
   }
   return cache[dev];
+}
+
+// Share of ONE XCD's CUs that the persistent forward of this shape occupies (aligned layout), or -1 if it would not run
+// persistent.  A launch that fills whole XCDs (the 512-wide LSTM: 1.0) stops EVERY other kernel from being dispatched
+// while it is resident -- workgroups are dealt to the XCDs round-robin and the dispatcher waits at the first one whose
+// XCD has no room (profiles/r03_xcd_dispatch_probe.txt) -- so nothing it waits for may be launched beside it.
+double ft_rnn_fwd_xcd_fill(int G, int B, int T, int H, void* ws, size_t ws_bytes) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  RnnFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.T = T; a.H = H; a.ND = 2; a.Bld = B; a.vec = H % 4 == 0;
+  double fill = -1.0;
+  g_fill_probe = &fill;
+  const int rc = G == 3 ? fwd_persistent<3>(a, ws, ws_bytes, nullptr) : fwd_persistent<4>(a, ws, ws_bytes, nullptr);
+  g_fill_probe = nullptr;
+  return rc == FT_OK ? fill : -1.0;
 }
 
 int ft_rnn_fwd_persistent(int G, RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {

@@ -6,6 +6,7 @@ tensors and raise if handed anything else -- there is no fallback path.
 """
 import contextlib
 import ctypes
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -145,7 +146,7 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
 
 
 def linear_multi_fwd(x: torch.Tensor, ws: List[torch.Tensor], biases: Optional[List[Optional[torch.Tensor]]],
-                     relu: bool = False, y_tm_B: int = 0) -> torch.Tensor:
+                     relu: bool = False, y_tm_B: int = 0, as_rows: int = 0) -> torch.Tensor:
     """Several Linear layers on one (batch-major) input, outputs concatenated along the last dim (one launch).
     y_tm_B > 0: x is [B,T,in] and the result is written time-major [T,B,sum(out)]."""
     _chk(x, 'x')
@@ -160,6 +161,12 @@ def linear_multi_fwd(x: torch.Tensor, ws: List[torch.Tensor], biases: Optional[L
     ba = _ptr_array(biases) if biases is not None else None
     oa = (ctypes.c_int * n)(*offs)
     fa = (ctypes.c_int * n)(*outs)
+    if as_rows:         # rounded like a launch over as_rows rows (ft_linear_multi_fwd_as)
+        assert not relu and not y_tm_B
+        _lib.call('ft_linear_multi_fwd_as', _p(x), in_f, n, ctypes.cast(wa, c_void_p),
+                  ctypes.cast(ba, c_void_p) if ba is not None else None, _p(y), sum(outs),
+                  ctypes.cast(oa, c_void_p), ctypes.cast(fa, c_void_p), rows, in_f, max(int(as_rows), 1), _stream())
+        return y
     _lib.call('ft_linear_multi_fwd', _p(x), in_f, n, ctypes.cast(wa, c_void_p),
               ctypes.cast(ba, c_void_p) if ba is not None else None, _p(y), sum(outs),
               ctypes.cast(oa, c_void_p), ctypes.cast(fa, c_void_p), rows, in_f, int(relu), 0, y_tm_B, _stream())
@@ -521,6 +528,30 @@ def lr_bwd(dy: torch.Tensor, cum: torch.Tensor, Tx: int) -> torch.Tensor:
     dx = torch.empty(B, Tx, C, device=dy.device, dtype=dy.dtype)
     _lib.call('ft_lr_bwd', _p(dy), _p(cum), _p(dx), B, Tx, Tm, C, _stream())
     return dx
+
+
+def lr_expand_tm(x: torch.Tensor, cum: torch.Tensor, Tm: int, pad_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B,Tx,C] -> TIME-major [Tm,B,C]; frames beyond an item's length hold pad_row (zeros if None)"""
+    _chk(x, 'x'); _chk(cum, 'cum', torch.int32)
+    B, Tx, C = x.shape
+    if pad_row is not None:
+        _chk(pad_row, 'pad_row')
+        assert pad_row.numel() == C
+    y = torch.empty(Tm, B, C, device=x.device, dtype=x.dtype)
+    _lib.call('ft_lr_expand_tm', _p(x), _p(cum), _p(pad_row), _p(y), B, Tx, Tm, C, _stream())
+    return y
+
+
+def lr_bwd_tm(dy: torch.Tensor, cum: torch.Tensor, Tx: int):
+    """dy TIME-major [Tm,B,C] -> (dx [B,Tx,C]: the frames of every token added up, in frame order; rows [B*Tx + B, C]:
+    dx's rows followed by one row per item with the sum of the frames beyond its last token -- what a column sum over
+    ALL frames has to run over)"""
+    _chk(dy, 'dy'); _chk(cum, 'cum', torch.int32)
+    Tm, B, C = dy.shape
+    rows = torch.empty(B * Tx + B, C, device=dy.device, dtype=dy.dtype)
+    dx = rows[:B * Tx].view(B, Tx, C)
+    _lib.call('ft_lr_bwd_tm', _p(dy), _p(cum), _p(dx), _p(rows[B * Tx:]), B, Tx, Tm, C, _stream())
+    return dx, rows
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -974,6 +1005,63 @@ def lstm_fwd(xp, whh_f, whh_r, bhh_f, bhh_r, lens: Optional[torch.Tensor], H: in
     _lib.call('ft_lstm_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(lens), _p(raw), _p(cst),
               _p(gates), B, T, H, _p(ws), nb, _stream())
     return raw, cst, gates
+
+
+# ---- recurrent layer forward with the input projection overlapped with the recurrence (ft_*_layer_fwd) ----
+_proj_streams = {}
+
+
+def rnn_overlap(rows: int, T: int) -> int:
+    """number of time chunks the input projection of a recurrent layer is cut into (0: projection in front, whole).
+    Off by default: measured neutral on the train step (the only layer it applies to, the postnet GRU, has a 130 us
+    projection; the 512-wide LSTM fills its XCDs and cannot be overlapped from another stream at all,
+    profiles/r03_xcd_dispatch_probe.txt).  FT_RNN_OVERLAP=1 turns it on, FT_RNN_CHUNKS sets the count (default 4)."""
+    if os.environ.get('FT_RNN_OVERLAP', '0') != '1' or rows < 8192 or T < 256:
+        return 0
+    return max(2, int(os.environ.get('FT_RNN_CHUNKS', '4')))
+
+
+def _proj_stream(device) -> 'torch.cuda.Stream':
+    key = torch.device(device).index or 0
+    st = _proj_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _proj_streams[key] = st
+    return st
+
+
+def lstm_layer_fwd(x, wih_f, wih_r, bih_f, bih_r, whh_f, whh_r, bhh_f, bhh_r, lens: Optional[torch.Tensor], H: int,
+                   save_gates: bool, nchunks: int):
+    """x [B,T,I] batch-major -> (raw, cst, gates) as lstm_fwd; the projection runs in time chunks beside the recurrence"""
+    _chk(x, 'x')
+    B, T, I = x.shape
+    dev = x.device
+    xp = torch.empty(T, B, 8 * H, device=dev, dtype=x.dtype)
+    raw = torch.empty(T, B, 2 * H, device=dev, dtype=x.dtype)
+    cst = torch.empty(T, B, 2 * H, device=dev, dtype=x.dtype)
+    gates = torch.empty(T, B, 2, 4 * H, device=dev, dtype=x.dtype) if save_gates else None
+    gate = torch.empty(16, device=dev, dtype=torch.int32)
+    ws, nb = _rnn_workspace(4, B, H, dev)
+    lead = int(os.environ.get('FT_RNN_REV_LEAD', str(nchunks // 2))) if lens is not None else 0
+    _lib.call('ft_lstm_layer_fwd', _p(x), I, _p(wih_f), _p(wih_r), _p(bih_f), _p(bih_r), _p(xp), _p(whh_f), _p(whh_r),
+              _p(bhh_f), _p(bhh_r), _p(lens), _p(raw), _p(cst), _p(gates), B, T, H, _p(ws), nb, _p(gate), nchunks, lead,
+              _stream(), _proj_stream(dev).cuda_stream)
+    return raw, cst, gates
+
+
+def gru_layer_fwd(x, wih_f, wih_r, bih_f, bih_r, whh_f, whh_r, bhh_f, bhh_r, H: int, save_gates: bool, nchunks: int):
+    _chk(x, 'x')
+    B, T, I = x.shape
+    dev = x.device
+    xp = torch.empty(T, B, 6 * H, device=dev, dtype=x.dtype)
+    out = torch.empty(T, B, 2 * H, device=dev, dtype=x.dtype)
+    gates = torch.empty(T, B, 2, 4 * H, device=dev, dtype=x.dtype) if save_gates else None
+    gate = torch.empty(16, device=dev, dtype=torch.int32)
+    ws, nb = _rnn_workspace(3, B, H, dev)
+    _lib.call('ft_gru_layer_fwd', _p(x), I, _p(wih_f), _p(wih_r), _p(bih_f), _p(bih_r), _p(xp), _p(whh_f), _p(whh_r),
+              _p(bhh_f), _p(bhh_r), _p(out), _p(gates), B, T, H, _p(ws), nb, _p(gate), nchunks, _stream(),
+              _proj_stream(dev).cuda_stream)
+    return out, gates
 
 
 def lstm_bwd(dout, raw, cst, gates, whhT_f, whhT_r, lens: Optional[torch.Tensor], H: int):

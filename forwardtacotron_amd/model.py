@@ -8,6 +8,7 @@ give the reference's exact names and default init); their forward() is never cal
 CPU / eager fallback: the model refuses to run if its tensors are not on a HIP device.
 """
 import math
+import os
 from pathlib import Path
 from typing import Any, Callable, Dict, List, Optional, Union
 
@@ -92,6 +93,32 @@ class LSTM(_RNNParams):
 
     def forward(self, x: torch.Tensor, lens: Optional[torch.Tensor], pad_value: float) -> torch.Tensor:
         return ops.BiLSTMFn.apply(x, lens, pad_value, *self.weights())
+
+    def forward_regulated(self, x: torch.Tensor, dur: torch.Tensor, lens: Optional[torch.Tensor],
+                          pad_value: float) -> torch.Tensor:
+        """self(LengthRegulator()(x, dur, lens), lens, pad_value) as one node, with the input projection formed per
+        token instead of per frame (ops.LRBiLSTMFn); x is the token-level input [B,Tx,I]"""
+        if not dur.is_contiguous() or dur.dtype != torch.float32:
+            raise H._lib.FtError('LengthRegulator: dur must be contiguous fp32 (it is clamped in place)')
+        return ops.LRBiLSTMFn.apply(x, dur, lens, pad_value, *self.weights())
+
+
+def regulate_and_decode(model, x: torch.Tensor, dur: torch.Tensor, mel_lens: Optional[torch.Tensor]) -> torch.Tensor:
+    """LengthRegulator + decoder LSTM of the ForwardTacotron variants (forward_tacotron.py:145-152), and the place where
+    trainer.TrainStep's staged backward cuts the graph.  FT_LR_LSTM_FUSED=0 keeps the two as separate nodes."""
+    staged = model.training and torch.is_grad_enabled() and getattr(model, 'stage_backward', False)
+    fused = os.environ.get('FT_LR_LSTM_FUSED', '1') != '0'
+    if not fused:
+        x = model.lr(x, dur, mel_lens)      # at max(mel_lens) frames, the length pad_packed_sequence returns (:147-152)
+    if staged:
+        # trainer.TrainStep runs the backward in three stages (postnet .. LSTM | predictors | LR .. prenet): the graph is
+        # cut here, below the (regulated) LSTM, and the trainer feeds the cut's gradient into the lower part itself
+        cut = x.detach().requires_grad_(True)
+        model._cut = (x, cut)
+        x = cut
+    if fused:
+        return model.lstm.forward_regulated(x, dur, mel_lens, model.padding_value)
+    return model.lstm(x, mel_lens, model.padding_value)
 
 
 class LengthRegulator(nn.Module):
@@ -333,14 +360,7 @@ class ForwardTacotron(nn.Module):
         x = ops.CondAddFn.apply(x, pitch, energy, self.pitch_proj.weight, self.pitch_proj.bias,
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
                                 self.energy_strength, True)                 # -> [B,Tx,2P]
-        x = self.lr(x, dur, mel_lens)       # at max(mel_lens) frames, the length pad_packed_sequence returns (:147-152)
-        if self.training and torch.is_grad_enabled() and getattr(self, 'stage_backward', False):
-            # trainer.TrainStep runs the backward in three stages (postnet .. LSTM | predictors | LR .. prenet): the graph
-            # is cut here, below the LSTM, and the trainer feeds the cut's gradient into the lower part itself
-            cut = x.detach().requires_grad_(True)
-            self._cut = (x, cut)
-            x = cut
-        x = self.lstm(x, mel_lens, self.padding_value)
+        x = regulate_and_decode(self, x, dur, mel_lens)
         mel = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)        # [B,T,n_mels]
         post = self.postnet(mel, time_major_out=True)                       # [T,B,2Q]
         post = ops.LinearFn.apply(post, self.post_proj.weight, None, B)     # -> [B,T,n_mels]

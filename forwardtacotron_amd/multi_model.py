@@ -12,7 +12,7 @@ import torch.nn as nn
 from . import hip as H
 from . import ops
 from .model import (BatchNormConv, CBHG, GRU, LSTM, LengthRegulator, NUM_CHARS_DEFAULT, PAD_VALUE, _dropout,
-                    _side_priority)
+                    _side_priority, regulate_and_decode)
 
 
 class SeriesPredictor(nn.Module):
@@ -162,14 +162,7 @@ class MultiForwardTacotron(nn.Module):
         x = ops.CondAddFn.apply(x, pitch, energy, self.pitch_proj.weight, self.pitch_proj.bias,
                                 self.energy_proj.weight, self.energy_proj.bias, self.pitch_strength,
                                 self.energy_strength, False)
-        x = self.lr(x, dur, mel_lens)       # at max(mel_lens) frames, the length pad_packed_sequence returns
-        if self.training and torch.is_grad_enabled() and getattr(self, 'stage_backward', False):
-            # trainer.TrainStep runs the backward in three stages (postnet .. LSTM | predictors | LR .. prenet): the graph
-            # is cut here, below the LSTM, and the trainer feeds the cut's gradient into the lower part itself
-            cut = x.detach().requires_grad_(True)
-            self._cut = (x, cut)
-            x = cut
-        x = self.lstm(x, mel_lens, self.padding_value)
+        x = regulate_and_decode(self, x, dur, mel_lens)
         mel = ops.LinearFn.apply(x, self.lin.weight, self.lin.bias)
         post = self.postnet(mel, time_major_out=True)
         post = ops.LinearFn.apply(post, self.post_proj.weight, None, B)

@@ -198,7 +198,7 @@ def flush_deferred() -> None:
                 sink.on_write(idx)
 
 
-def _emit(w: torch.Tensor, compute, deps=(), heavy=True, late: bool = False):
+def _emit(w: torch.Tensor, compute, deps=(), heavy=True, late: bool = False, inline_ok: bool = True):
     """Produces the gradient of parameter `w`: compute(out) must overwrite `out` (same shape as w).
     Without a sink: returns a fresh tensor (autograd accumulates it).  With a sink: writes the flat-buffer
     view (on the side stream when `heavy`) and returns None.  heavy='light': a small reduction (bias gradient) that nothing
@@ -218,7 +218,7 @@ def _emit(w: torch.Tensor, compute, deps=(), heavy=True, late: bool = False):
     if heavy == 'light':
         heavy = _SINK.defer and bool(deps) and os.environ.get('FT_BIAS_GRADS_SIDE', '1') == '1'
     side = _SINK.stream if heavy else None
-    if side is not None and deps and deps[0].numel() // deps[0].shape[-1] <= _SINK.inline_rows:
+    if side is not None and inline_ok and deps and deps[0].numel() // deps[0].shape[-1] <= _SINK.inline_rows:
         side = None                     # short (token-side) operands: see GradSink.inline_rows
     if side is None:
         compute(view)
@@ -599,8 +599,13 @@ class BiGRUFn(Function):
         x = _c(x)
         Hh = w_hh_f.shape[1]
         train = any(ctx.needs_input_grad)
-        xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
-        out, gates = H.gru_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, Hh, save_gates=train)
+        nch = H.rnn_overlap(x.shape[0] * x.shape[1], x.shape[1])
+        if nch:     # the projection runs in time chunks beside the recurrence (ft_gru_layer_fwd)
+            out, gates = H.gru_layer_fwd(x, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, w_hh_r, b_hh_f, b_hh_r, Hh,
+                                         save_gates=train, nchunks=nch)
+        else:
+            xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
+            out, gates = H.gru_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, Hh, save_gates=train)
         if train:
             ctx.save_for_backward(x, out, gates, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.Hh = Hh
@@ -627,8 +632,13 @@ class BiLSTMFn(Function):
         x = _c(x)
         Hh = w_hh_f.shape[1]
         train = any(ctx.needs_input_grad)
-        xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
-        raw, cst, gates = H.lstm_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens, Hh, save_gates=train)
+        nch = H.rnn_overlap(x.shape[0] * x.shape[1], x.shape[1])
+        if nch:     # the projection runs in time chunks beside the recurrence (ft_lstm_layer_fwd)
+            raw, cst, gates = H.lstm_layer_fwd(x, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens,
+                                               Hh, save_gates=train, nchunks=nch)
+        else:
+            xp = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], y_tm_B=x.shape[0])
+            raw, cst, gates = H.lstm_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens, Hh, save_gates=train)
         if train:
             ctx.save_for_backward(x, raw, cst, gates, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
                                   b_ih_r, b_hh_r)
@@ -650,6 +660,88 @@ class BiLSTMFn(Function):
         # (one of the decoder LSTM's four weight gradients may run at the end of the main stream's chain: GradSink.late)
         dx, g = _rnn_param_grads(dg, dg, x, raw, 4, Hh, params, ctx.needs_input_grad[0], late_last=True)
         return (dx, None, None, *g)
+
+
+def lr_frames(total: torch.Tensor, pack_lens: Optional[torch.Tensor]) -> int:
+    """frames the LengthRegulator's result is produced at (one host sync, like the reference): see LengthRegulateFn"""
+    if total.numel() == 0:
+        return 0
+    if pack_lens is None:
+        return int(total.max().item())
+    Tm, Lmax = torch.stack([total.max().long(), pack_lens.max().long()]).tolist()
+    if Lmax > Tm:
+        raise H._lib.FtError(f'LengthRegulator: an item is to be packed with {Lmax} frames but the rounded '
+                             f'durations expand to at most {Tm} (the reference fails in its packed LSTM here)')
+    return Lmax
+
+
+class LRBiLSTMFn(Function):
+    """LengthRegulator -> pack_padded_sequence -> nn.LSTM(bidirectional) -> pad_packed_sequence as ONE node
+    (forward_tacotron.py:145-152, common_layers.py:17-24).
+
+    The LSTM's input projection x W_ih^T + b_ih is a row-wise linear map and the regulator only REPEATS rows, so the two
+    commute: the projection is formed once per TOKEN (B x Tx = 4,096 rows at the benchmark shape instead of 26,912
+    frames -- 6.6x fewer flops, by the same kernel in the same k order, so every row has exactly the bits the frame-level
+    GEMM gives it) and ft_lr_expand_tm writes it out per frame, straight into the recurrence's time-major layout
+    (frames beyond an item's length hold the bias: the projection of the regulator's zero rows).  Backward: the
+    d(pre-activations) of each token's frames are added up first (ft_lr_bwd_tm -- what the regulator's backward does to
+    any gradient), and W_ih's input / weight / bias gradients are token-level GEMMs and sums.  The forward is
+    bit-identical to LengthRegulateFn + BiLSTMFn; the backward adds the same numbers in another order (frames of a token
+    first), an fp32-class difference.  x is the token-level input [B,Tx,I]; `dur` is clamped in place like every
+    LengthRegulator input; lens = the lengths the result is packed with (None: padded length, forward_tacotron.py:224)."""
+
+    @staticmethod
+    def forward(ctx, x, dur, lens, pad_value, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        x = _c(x)
+        Hh = w_hh_f.shape[1]
+        train = any(ctx.needs_input_grad)
+        cum, total = H.lr_scan(dur)
+        Tm = lr_frames(total, lens)
+        # [B,Tx,8H], one row per token, by the kernel the frame-level launch (B * Tm rows) would take
+        P = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], as_rows=max(1, x.shape[0] * Tm))
+        xp = H.lr_expand_tm(P, cum, Tm, torch.cat([b_ih_f.detach(), b_ih_r.detach()]))
+        raw, cst, gates = H.lstm_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens, Hh, save_gates=train)
+        if train:
+            ctx.save_for_backward(x, cum, raw, cst, gates, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
+                                  b_ih_r, b_hh_r)
+        ctx.Hh = Hh
+        ctx.has_lens = lens is not None
+        return H.fill_padded(raw, lens, float(pad_value))
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, cum, raw, cst, gates, lens = ctx.saved_tensors[:6]
+        params = ctx.saved_tensors[6:]
+        Hh = ctx.Hh
+        B, Tx, I = x.shape
+        T = raw.shape[0]
+        GH = 4 * Hh
+        dout_tm = H.bt_transpose(_c(dout), True)
+        pend = flush_begin()
+        dg = H.lstm_bwd(dout_tm, raw, cst, gates, H.transpose2d(params[1]), H.transpose2d(params[5]),
+                        lens if ctx.has_lens else None, Hh)
+        flush_end(pend)
+        dP, dP_all = H.lr_bwd_tm(dg, cum, Tx)                 # [B,Tx,8H]: each token's frames added up
+        db = H.colsum(dP_all)                                 # all frames (b_ih and b_hh see the same sum)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            H.linear_bwd_data_multi([dP.data_ptr(), dP.data_ptr() + GH * _F4], 2 * GH, [params[0], params[4]], dx,
+                                    B * Tx, GH)
+        gb = _emit_copies([params[2], params[3], params[6], params[7]], [db[0:GH], db[0:GH], db[GH:], db[GH:]])
+        grads: List[Optional[torch.Tensor]] = []
+        for d in range(2):
+            w_ih, w_hh = params[4 * d], params[4 * d + 1]
+            px = dP.data_ptr() + d * GH * _F4
+            ph = dg.data_ptr() + d * GH * _F4
+            # (token-level operands, but not the step's tail: they go to the side stream like every frame-side gradient)
+            g_ih = _emit(w_ih, lambda out, px=px: H.linear_bwd_weight_raw(px, 2 * GH, x.data_ptr(), I, out, B * Tx, I, GH),
+                         (dP, x), inline_ok=False)
+            g_hh = _emit(w_hh, lambda out, ph=ph, d=d: H.linear_bwd_weight_raw(
+                ph, 2 * GH, raw.data_ptr() + d * Hh * _F4, 2 * Hh, out, B * T, Hh, GH, B=B, T=T,
+                x_shift=-1 if d == 0 else 1, dy_tm=True, x_tm=True), (dg, raw), late=d == 1)
+            grads += [g_ih, g_hh, gb[2 * d], gb[2 * d + 1]]
+        return (dx, None, None, None, *grads)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -694,16 +786,7 @@ class LengthRegulateFn(Function):
     def forward(ctx, x, dur, pack_lens=None):
         x = _c(x)
         cum, total = H.lr_scan(dur)
-        if total.numel() == 0:
-            Tm = 0
-        elif pack_lens is None:
-            Tm = int(total.max().item())
-        else:
-            Tm, Lmax = torch.stack([total.max().long(), pack_lens.max().long()]).tolist()
-            if Lmax > Tm:
-                raise H._lib.FtError(f'LengthRegulator: an item is to be packed with {Lmax} frames but the rounded '
-                                     f'durations expand to at most {Tm} (the reference fails in its packed LSTM here)')
-            Tm = Lmax
+        Tm = lr_frames(total, pack_lens)
         ctx.save_for_backward(cum)
         ctx.Tx = x.shape[1]
         return H.lr_expand(x, cum, Tm)

@@ -56,6 +56,13 @@ int ft_linear_fwd(const float* x, long ldx, const float* w, const float* bias, f
 int ft_linear_multi_fwd(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
                         float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, int relu,
                         int x_tm_B, int y_tm_B, void* stream);
+/* The same product, computed by the kernel that a launch over `as_rows` rows of the same layers would take
+ * (the launcher picks 128x128 bf16-split or 64x64 f32 tiles by size, and the two round differently): the LengthRegulator
+ * repeats rows, so a projection of its RESULT can be formed on its input with the bits the frame-level launch would give
+ * every row (ops.LRBiLSTMFn). */
+int ft_linear_multi_fwd_as(const float* x, long ldx, int ntasks, const float* const* w, const float* const* bias,
+                           float* y, long ldy, const int* col_offset, const int* out_f, int rows, int in_f, long as_rows,
+                           void* stream);
 /* dx[rows,in_f] (+)= dy[rows,out_f] * w[out_f,in_f] ; w_transposed = 1: `w` points at w^T [in_f,out_f] instead
  * (both operands then have the contraction index contiguous -- the form the bf16-split MFMA kernel takes) */
 int ft_linear_bwd_data(const float* dy, long lddy, const float* w, float* dx, long lddx, int rows, int in_f,
@@ -192,6 +199,18 @@ int ft_lr_expand(const float* x, const int* cum, float* y, int* src_idx, int B, 
                  void* stream);
 /* dx[b,j,:] = sum of dy rows of token j (fixed order) */
 int ft_lr_bwd(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, void* stream);
+/* The same pair with the FRAME side time-major ([Tm,B,C]) -- the layout of the recurrences' buffers.  They carry the
+ * decoder LSTM's input projection through the LengthRegulator: the projection is a row-wise linear map and the
+ * regulator only repeats rows, so x_tok * W_ih^T + b_ih is formed once per TOKEN (4,096 rows at the benchmark shape
+ * instead of 26,912 frames; same kernel, same k order: every row has the bits the frame-level GEMM gives it) and
+ * ft_lr_expand_tm writes it out per frame; pad_row (C floats, optional) is what frames beyond an item's length hold
+ * -- the projection of the regulator's zero rows is the bias.  Backward: ft_lr_bwd_tm sums d(pre-activations) over each
+ * token's frames, and the input / weight gradients of W_ih are token-level GEMMs (forward_tacotron.py:145-152). */
+int ft_lr_expand_tm(const float* x, const int* cum, const float* pad_row, float* y, int B, int Tx, int Tm, int C,
+                    void* stream);
+/* dtail (optional, [B,C]): per item, the sum of the frames beyond its last token (t >= total[b]) -- they reach no token,
+ * but the bias gradients are column sums over ALL frames (an unpacked LSTM runs over those frames too) */
+int ft_lr_bwd_tm(const float* dy, const int* cum, float* dx, float* dtail, int B, int Tx, int Tm, int C, void* stream);
 
 /* ---- nn.BatchNorm1d of BatchNormConv (common_layers.py:51,57) on channels-last y[B,Tbuf,C] ----------- */
 /* group > 0 = CBHG bank buffer [B,T+1,K*group]: channel c belongs to kernel size k=c/group+1 and has
@@ -390,6 +409,25 @@ int ft_lstm_fwd(const float* xp, const float* whh_f, const float* whh_r, const f
 int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, const float* gates,
                 const float* whhT_f, const float* whhT_r, const long* lens, float* dgates, float* carry, int B, int T,
                 int H, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- a recurrent LAYER's forward with the input projection overlapped with the recurrence (no reference counterpart:
+ * nn.LSTM / nn.GRU, forward_tacotron.py:96-99,147-152 / common_layers.py:89,123, run the projection in front).
+ * x [B,T,in_f] batch-major; xp [T,B,2*G*H] (scratch for the projection, G = 4 | 3); the other arguments as in
+ * ft_lstm_fwd / ft_gru_fwd.  x * W_ih^T + b_ih is formed in `nchunks` time chunks: chunk 0 of both directions on
+ * `stream`, the others on `side_stream`, each followed by a one-thread kernel that raises gate[direction]; the
+ * persistent recurrence is launched right behind chunk 0 and polls (bounded) the gate word before it reads a row of a
+ * chunk it has not seen complete.  gate: >= 2 device words owned by the call.  rev_lead: chunks of the reverse direction
+ * issued first (a packed item of length L starts at t = L - 1).  nchunks < 2 / side_stream NULL or == stream: the
+ * projection runs whole, in front.  If the persistent form is refused, `stream` first waits for all chunks.  Results are
+ * bit-identical to ft_linear_multi_fwd + ft_lstm_fwd / ft_gru_fwd. */
+int ft_lstm_layer_fwd(const float* x, int in_f, const float* wih_f, const float* wih_r, const float* bih_f,
+                      const float* bih_r, float* xp, const float* whh_f, const float* whh_r, const float* bhh_f,
+                      const float* bhh_r, const long* lens, float* out_raw, float* cstate, float* gates, int B, int T,
+                      int H, void* workspace, size_t workspace_bytes, unsigned* gate, int nchunks, int rev_lead,
+                      void* stream, void* side_stream);
+int ft_gru_layer_fwd(const float* x, int in_f, const float* wih_f, const float* wih_r, const float* bih_f,
+                     const float* bih_r, float* xp, const float* whh_f, const float* whh_r, const float* bhh_f,
+                     const float* bhh_r, float* out, float* gates, int B, int T, int H, void* workspace,
+                     size_t workspace_bytes, unsigned* gate, int nchunks, void* stream, void* side_stream);
 int ft_fill_padded(const float* raw, const long* lens, float* out, int B, int T, int C, float pad, void* stream);
 int ft_mask_rows(const float* src, const long* lens, float* dst, int B, int T, int C, void* stream);
 /* [B,T,C] -> [T,B,C] (dst_time_major = 1) or back (0) */
