@@ -234,17 +234,13 @@ int ft_highway_bwd_data(const float* d12, const float* w1, const float* w2, int 
 
 // dx (+)= sum_i dy_i * w_i : several Linear layers that read the same input (highway W1/W2, the two directions of a
 // recurrence's input projection) hand their data gradients back in ONE chained launch
-int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
-                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
-                             void* stream) {
-  FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_bwd_data_multi: ntasks %d out of range", ntasks);
-  if (check_tm("linear_bwd_data_multi", rows, dy_tm_B) || check_tm("linear_bwd_data_multi", rows, dx_tm_B))
-    return FT_ERR_ARG;
-  FtGemmBatch b;
+static void data_multi_batch(FtGemmBatch& b, int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx,
+                             long lddx, int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B,
+                             int w_transposed) {
   memset(&b, 0, sizeof(b));
   for (int i = 0; i < ntasks; ++i) {
     FtGemmTask& t = b.t[i];
-    t.A = dy[i]; t.B = w[i]; t.C = dx;
+    t.A = dy ? dy[i] : nullptr; t.B = w ? w[i] : nullptr; t.C = dx;
     t.lda = lddy; t.ldb = w_transposed ? out_f : in_f; t.ldc = lddx;
     t.M = rows; t.N = in_f; t.K = out_f; t.taps = 1;
     t.amap = ft_rowmap_layout(rows, dy_tm_B);
@@ -252,6 +248,38 @@ int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, cons
     t.accumulate = accumulate;
   }
   b.chain = ntasks > 1 ? ntasks : 0;
+}
+
+int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
+                             int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
+                             void* stream) {
+  FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_bwd_data_multi: ntasks %d out of range", ntasks);
+  if (check_tm("linear_bwd_data_multi", rows, dy_tm_B) || check_tm("linear_bwd_data_multi", rows, dx_tm_B))
+    return FT_ERR_ARG;
+  FtGemmBatch b;
+  data_multi_batch(b, ntasks, dy, lddy, w, dx, lddx, rows, in_f, out_f, accumulate, dy_tm_B, dx_tm_B, w_transposed);
+  return ft_launch_gemm_rows(&b, ntasks, !w_transposed, (hipStream_t)stream);
+}
+
+// The same product with scratch for split-K: few output tiles (token-side rows) and a long contraction (the recurrent
+// layers' 2 x 4H pre-activation gradients) leave most of the chip idle in one pass over K
+size_t ft_linear_bwd_data_multi_workspace(int ntasks, int rows, int in_f, int out_f, void* stream) {
+  if (ntasks < 1 || ntasks > FT_MAX_TASKS) return 0;
+  FtGemmBatch b;
+  data_multi_batch(b, ntasks, nullptr, out_f, nullptr, nullptr, in_f, rows, in_f, out_f, 0, 0, 0, 1);
+  return ft_rows_ksplit_floats(b, ntasks, (hipStream_t)stream) * sizeof(float);
+}
+int ft_linear_bwd_data_multi_ws(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
+                                int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "linear_bwd_data_multi: ntasks %d out of range", ntasks);
+  if (check_tm("linear_bwd_data_multi", rows, dy_tm_B) || check_tm("linear_bwd_data_multi", rows, dx_tm_B))
+    return FT_ERR_ARG;
+  FtGemmBatch b;
+  data_multi_batch(b, ntasks, dy, lddy, w, dx, lddx, rows, in_f, out_f, accumulate, dy_tm_B, dx_tm_B, w_transposed);
+  if (workspace && w_transposed &&
+      workspace_bytes >= ft_rows_ksplit_floats(b, ntasks, (hipStream_t)stream) * sizeof(float))
+    b.ksplit_slab = static_cast<float*>(workspace);
   return ft_launch_gemm_rows(&b, ntasks, !w_transposed, (hipStream_t)stream);
 }
 
@@ -529,6 +557,21 @@ int ft_conv_bank_bwd_data(const float* dy, long lddy, const float* wp_all, float
     woff += (long)k * C * Cin;
   }
   b.chain = partials ? 0 : K;
+  if (partials && wp_transposed) {
+    // better than per-member partials (member k does k taps: sixteen-fold imbalance between the tasks of one launch):
+    // ONE chained product whose stage sequence is cut into equal ranges (split-K, FtGemmBatch.ksplit_slab)
+    FtGemmBatch c = b;
+    for (int i = 0; i < K; ++i) {
+      c.t[i].C = dx;
+      c.t[i].ldc = lddx;
+    }
+    c.chain = K;
+    const size_t need = ft_rows_ksplit_floats(c, K, (hipStream_t)stream) * sizeof(float);
+    if (need > 0 && need <= workspace_bytes) {
+      c.ksplit_slab = part;
+      return ft_launch_gemm_rows(&c, K, false, (hipStream_t)stream);
+    }
+  }
   int rc = ft_launch_gemm_rows(&b, K, !wp_transposed, (hipStream_t)stream);
   if (rc || !partials) return rc;
   return ft_launch_slab_sum(part, dx, B * T, Cin, K, lddx, (hipStream_t)stream);

@@ -77,6 +77,13 @@ struct FtGemmBatch {
   // launch's own size; 1 = 64, 2 = 128 -- a GEMM issued in row chunks then rounds exactly like the same GEMM issued
   // whole (ft_*_layer_fwd; ft_rows_tile_is_big gives the whole launch's choice)
   int force_tile;
+  // Split-K of a single-task or chained NT launch with FEW output tiles and a LONG contraction (the token-side data
+  // gradients: 4,096 rows): ksplit_slab != null offers ft_rows_ksplit_floats() floats of scratch; the launcher then may cut
+  // the stage sequence into ksplit ranges (grid z), every range writing its raw partial tile to slab[z][M][N], and a second
+  // launch adds the partials in range order and applies bias / accumulate / the output row map.  ksplit is set by the
+  // launcher (0 / 1: not split).  Sums the same products in another order than the unsplit launch: callers are gradients.
+  float* ksplit_slab;
+  int ksplit;
   int hw_mode, hw_C;
   const float* hw_x;
   const float* hw_b1;
@@ -240,6 +247,10 @@ __device__ __forceinline__ FtTnWho ft_tn_who(const FtGemmTNTask& T, int S, int B
 static inline bool ft_rows_tile_is_big(long tiles128, int maxM, int maxN) { return tiles128 >= 192 && maxN > 64 && maxM > 64; }
 static_assert(sizeof(FtGemmBatch) <= 4080, "FtGemmBatch travels as a kernel argument (4 KB limit)");
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream);
+// scratch (floats) a launch of these tasks can use for split-K (0: it would not be split)
+size_t ft_rows_ksplit_floats(const FtGemmBatch& batch, int ntasks, hipStream_t stream);
+int ft_launch_ksplit_reduce(const float* slab, int S, const FtGemmTask& t, hipStream_t stream);
+bool ft_rows_b3p_ok(const FtGemmBatch& batch, int ntask);
 // fp32 on the bf16 matrix pipe (exact 3-way operand split, ft_gemm_b3.hip); NT + FAST launches, FT_GEMM_B3=0 disables
 int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream);
 int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per_split, int tm, dim3 grid,

@@ -632,6 +632,37 @@ size_t ft_gemm_tn_workspace_floats(const FtGemmTNTask& t) {
   return (size_t)(p0.S > p1.S ? p0.S : p1.S) * t.taps * (t.nz > 1 ? t.nz : 1) * t.M * t.N;
 }
 
+// Split-K plan of an NT launch (FtGemmBatch.ksplit_slab): only single-task / chained products with few 128x128 output
+// tiles, a long stage sequence (>= 128 stages of 16 k) and a plain epilogue; S ranges of >= 32 stages each, S * tiles <= the
+// stream's slots
+static int rows_ksplit_plan(const FtGemmBatch& b, int ntasks, hipStream_t stream) {
+  static const bool enabled = [] {                   // FT_GEMM_KSPLIT=0: never split (A/B knob)
+    const char* e = getenv("FT_GEMM_KSPLIT");
+    return !(e && e[0] == '0');
+  }();
+  const bool chained = b.chain > 1;
+  if (!enabled || !(chained ? b.chain == ntasks : ntasks == 1) || !ft_gemm_b3_enabled()) return 1;
+  const FtGemmTask& t0 = b.t[0];
+  if (t0.nz > 1 || t0.relu || t0.scale || t0.stat || b.hw_mode || b.relu_mask || t0.N % 4 != 0 || t0.M <= 64 || t0.N <= 64) return 1;
+  if (!ft_rows_b3p_ok(b, ntasks)) return 1;
+  long stages = 0;
+  for (int i = 0; i < ntasks; ++i) stages += (long)b.t[i].taps * ft_cdiv(b.t[i].K, 16);
+  const long tiles = (long)ft_cdiv(t0.M, 128) * ft_cdiv(t0.N, 128);
+  const long slots = ft_stream_slots(stream);
+  if (stages < 128) return 1;                      // (a short contraction gains nothing: launch + second pass)
+  long S = slots / (tiles > 0 ? tiles : 1);
+  if (S > stages / 32) S = stages / 32;
+  if (S > 16) S = 16;
+  if (S < 2) return 1;
+  const long per = (stages + S - 1) / S;
+  return (int)((stages + per - 1) / per);            // no empty range
+}
+
+size_t ft_rows_ksplit_floats(const FtGemmBatch& batch, int ntasks, hipStream_t stream) {
+  const int S = rows_ksplit_plan(batch, ntasks, stream);
+  return S > 1 ? (size_t)S * batch.t[0].M * batch.t[0].N : 0;
+}
+
 int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStream_t stream) {
   FT_REQUIRE(ntasks >= 1 && ntasks <= FT_MAX_TASKS, "gemm_rows: bad task count %d", ntasks);
   int maxM = 0, maxN = 0;
@@ -666,9 +697,24 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
   } else {
     batch->chain = 0;
   }
-  const bool big = batch->force_tile ? batch->force_tile == 2 : ft_rows_tile_is_big(tiles128, maxM, maxN);
+  bool big = batch->force_tile ? batch->force_tile == 2 : ft_rows_tile_is_big(tiles128, maxM, maxN);
+  batch->ksplit = 0;
+  if (batch->ksplit_slab) {
+    bool ok = !b_ncontig && ft_gemm_precision() == 0;
+    for (int i = 0; i < ntasks && ok; ++i) {
+      const FtGemmTask& t = batch->t[i];
+      ok = (t.lda % 4 == 0) && (((uintptr_t)t.A) % 16 == 0) && (t.ldb % 4 == 0) && (t.b_tap_stride % 4 == 0) &&
+           (((uintptr_t)t.B) % 16 == 0) && t.K % 4 == 0;
+    }
+    const int S = ok ? rows_ksplit_plan(*batch, ntasks, stream) : 1;
+    if (S > 1) {
+      batch->ksplit = S;
+      big = true;
+    }
+  }
   const int bm = big ? 128 : 64;
   dim3 grid(ft_cdiv(maxM, bm), ft_cdiv(maxN, bm), chained ? 1 : (ntasks == 1 ? batch->t[0].nz : ntasks));
+  if (batch->ksplit > 1) grid.z = batch->ksplit;
   FT_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_rows: grid too large");
   bool fast = true;
   for (int i = 0; i < ntasks; ++i) {
@@ -710,7 +756,9 @@ int ft_launch_gemm_rows(FtGemmBatch* batch, int ntasks, bool b_ncontig, hipStrea
     log.end(b_ncontig ? "rowsNN" : (b3 ? (ft_gemm_precision() == 1 ? "rowsBF" : "rowsB3") : "rowsNT"), maxM, maxN, sk, ntasks, batch->t[0].nz,
             big ? "128" : "64", fl);
   }
-  return ft_check_launch("gemm_rows");
+  int rc = ft_check_launch("gemm_rows");
+  if (rc == FT_OK && batch->ksplit > 1) rc = ft_launch_ksplit_reduce(batch->ksplit_slab, batch->ksplit, batch->t[0], stream);
+  return rc;
 }
 
 int ft_launch_slab_sum(const float* slab, float* dst, int M, int N, int S, long ldm, hipStream_t stream) {

@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
     by = w - bx * gy;
   }
   const bool zbatch = batch.t[0].nz > 1;
-  const FtGemmTask& T = batch.t[zbatch ? 0 : bz];
+  const int ksplit = batch.ksplit > 1 ? batch.ksplit : 1;       // split-K: z = stage range (FtGemmBatch.ksplit_slab)
+  const FtGemmTask& T = batch.t[(zbatch || ksplit > 1) ? 0 : bz];
   const float* TA = T.A;
   const float* TB = T.B;
   float* TC = T.C;
@@ -444,6 +445,23 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   int nch = 0;
   for (int i = 0; i < nchain; ++i) nch += batch.t[i].taps * ((batch.t[i].K + SK - 1) / SK);
   if (nchain == 1) nch = taps * kch;
+  if (ksplit > 1) {                                  // this workgroup's range of the stage sequence: move the cursor there
+    const int per = (nch + ksplit - 1) / ksplit;
+    int rem = bz * per;
+    nch = nch - rem < per ? nch - rem : per;
+    if (nch < 0) nch = 0;
+    while (l_task < nchain - 1) {
+      const int n = batch.t[l_task].taps * ((batch.t[l_task].K + SK - 1) / SK);
+      if (rem < n) break;
+      rem -= n;
+      ++l_task;
+    }
+    if (l_task > 0) setup(batch.t[l_task], batch.t[l_task].A, batch.t[l_task].B);
+    l_tap = rem / kch;
+    l_kc = rem - l_tap * kch;
+    set_tap();
+    if (ktail && kch > 1 && l_kc == kch - 1) mask_tail();
+  }
 
   struct Regs { u32x4 a0, a1, b0, b1, b2; };
   // issue the four loads of the stage under the cursor.  No branch in here (the loads, the split of the older register
@@ -557,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   unsigned short* const buf0 = smem;
   unsigned short* const buf1 = smem + BUF;
   Regs R0, R1;
+  if (nch > 0) {
   load_stage(R0);
   advance();
   if (nch > 1) {
@@ -621,13 +640,56 @@ __global__ __launch_bounds__(256, 2) void ft_gemm_rows_b3p_kernel(FtGemmBatch ba
   } else {
     mfma_on(fa, fb);
   }
+  }                                                  // (nch > 0)
   __syncthreads();                                   // the epilogue's statistics scratch aliases the tiles
+  if (ksplit > 1) {                                  // raw partial tile -> slab[z][M][N]; ft_ksplit_reduce_kernel finishes
+    float* out = batch.ksplit_slab + (long)bz * tM * tN;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * 32 * TN + 32 * j + l31;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 32 * TM + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+          if (row < tM && col < tN) out[(long)row * tN + col] = acc[i][j][e];
+        }
+    }
+    return;
+  }
   if (batch.hw_mode) {                                // highway gate / gate gradient in the epilogue (ft_gemm.h)
     ft_highway_epilogue<TM, TN>(batch, T, TC, acc, reinterpret_cast<float*>(smem), m0, n0, tid);
     return;
   }
   rows_b3_epilogue<TM, TN>(T, TC, acc, smem, m0, n0, tM, tN, tid, bx, batch.relu_mask);
 }
+
+// second launch of a split-K NT product: C[cmap(row)][col] (+)= sum_z slab[z][row][col] + bias, in range order
+__global__ __launch_bounds__(256) void ft_ksplit_reduce_kernel(const float* __restrict__ slab, int S, FtGemmTask T) {
+  const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long total = (long)T.M * T.N;
+  if (idx >= total) return;
+  const int row = (int)(idx / T.N), col = (int)(idx - (long)row * T.N);      // N % 4 == 0: the four columns share a row
+  float4 a = *reinterpret_cast<const float4*>(slab + idx);
+  for (int z = 1; z < S; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(slab + (long)z * total + idx);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (T.bias) {
+    a.x += T.bias[col]; a.y += T.bias[col + 1]; a.z += T.bias[col + 2]; a.w += T.bias[col + 3];
+  }
+  long crow = row;
+  if (T.cmap.bstride != 0) {
+    const int cb = row / T.cmap.Tlog;
+    crow = (long)cb * T.cmap.bstride + (long)(row - cb * T.cmap.Tlog) * T.cmap.tstride;
+  }
+  float* cp = T.C + crow * T.ldc + col;
+  if (T.accumulate) {
+    a.x += cp[0]; a.y += cp[1]; a.z += cp[2]; a.w += cp[3];
+  }
+  cp[0] = a.x; cp[1] = a.y; cp[2] = a.z; cp[3] = a.w;
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // TN (weight gradients): slab[z][m][n] = sum_{r in slice} A[map_a(r)][m] * B[map_b,tap(r)][n].  The contraction index
@@ -1152,22 +1214,35 @@ int ft_launch_gemm_tn_b3(const FtGemmTNTask& t, float* slab, int S, int rows_per
 }
 
 // NT, FAST (16-B aligned operands, K % 4 == 0) launches only; grid / tile choice made by ft_launch_gemm_rows
-int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream) {
-  const bool bf16 = ft_gemm_precision() == 1;
+int ft_launch_ksplit_reduce(const float* slab, int S, const FtGemmTask& t, hipStream_t stream) {
+  const long quads = ((long)t.M * t.N + 3) / 4;
+  hipLaunchKernelGGL(ft_ksplit_reduce_kernel, dim3(ft_cdiv(quads, 256)), dim3(256), 0, stream, slab, S, t);
+  return ft_check_launch("ksplit_reduce");
+}
+
+// may these tasks take the pipelined 128x128 kernel (the only one that implements split-K)?
+bool ft_rows_b3p_ok(const FtGemmBatch& batch, int ntask) {
   static const bool pipelined = [] {                 // FT_GEMM_PIPE=0: the two-barrier 128x128 kernel (A/B knob)
     const char* e = getenv("FT_GEMM_PIPE");
     return !(e && e[0] == '0');
   }();
   // the pipelined kernel addresses a tile's rows with 32-bit byte offsets from the tile's first row (buffer loads)
   bool span_ok = true;
-  const int ntask = batch.chain > 1 ? batch.chain : (int)grid.z;
   for (int i = 0; i < (batch.t[0].nz > 1 ? 1 : ntask) && i < FT_MAX_TASKS; ++i) {
     const FtGemmTask& t = batch.t[i];
     const long tl = t.amap.Tlog, ts = t.amap.tstride, bs = t.amap.bstride;
     const long rows = (tl < 128 ? tl : 128) * ts + (128 / tl + 2) * bs + tl * ts;     // bound on a tile's physical row span
     span_ok = span_ok && ts >= 0 && bs >= 0 && rows * t.lda * 4 < (1L << 31) && 128L * t.ldb * 4 < (1L << 31);
   }
-  if (big && pipelined && span_ok) {
+  return pipelined && span_ok;
+}
+
+int ft_launch_gemm_rows_b3(const FtGemmBatch& batch, bool big, dim3 grid, hipStream_t stream) {
+  const bool bf16 = ft_gemm_precision() == 1;
+  const int ntask = batch.chain > 1 ? batch.chain : (batch.ksplit > 1 ? 1 : (int)grid.z);
+  const bool p_ok = ft_rows_b3p_ok(batch, ntask);
+  FT_REQUIRE(batch.ksplit <= 1 || (big && p_ok), "gemm_rows: split-K planned for a launch the pipelined kernel cannot take");
+  if (big && p_ok) {
     if (bf16) hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<1>), grid, dim3(256), 0, stream, batch);
     else hipLaunchKernelGGL((ft_gemm_rows_b3p_kernel<3>), grid, dim3(256), 0, stream, batch);
   } else if (big) {

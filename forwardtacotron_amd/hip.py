@@ -223,6 +223,12 @@ def linear_bwd_data_multi(dy_ptrs: Sequence[int], lddy: int, ws: Sequence[torch.
     flag = 1 if NT_GRADS and all(w.shape[0] % 4 == 0 for w in ws) else 0
     wts = [transpose2d(w) for w in ws] if flag else list(ws)
     wa = _ptr_array(wts)
+    nbytes = _lib.lib().ft_linear_bwd_data_multi_workspace(n, rows, in_f, out_f, _stream()) if flag else 0
+    if nbytes:          # few output tiles, long contraction: split-K (scratch from the stream's workspace)
+        ws = workspace(nbytes, dx.device)
+        _lib.call('ft_linear_bwd_data_multi_ws', n, ctypes.cast(da, c_void_p), lddy, ctypes.cast(wa, c_void_p), _p(dx),
+                  in_f, rows, in_f, out_f, int(accumulate), dy_tm_B, dx_tm_B, flag, _p(ws), ws.numel(), _stream())
+        return
     _lib.call('ft_linear_bwd_data_multi', n, ctypes.cast(da, c_void_p), lddy, ctypes.cast(wa, c_void_p), _p(dx), in_f,
               rows, in_f, out_f, int(accumulate), dy_tm_B, dx_tm_B, flag, _stream())
 

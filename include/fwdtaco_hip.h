@@ -119,6 +119,14 @@ int ft_conv1d_bwd_data_relu(const float* dy, long lddy, const float* wp, const f
 int ft_linear_bwd_data_multi(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
                              int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
                              void* stream);
+/* The same product with scratch for split-K (ft_linear_bwd_data_multi_workspace bytes; 0 = it would not be split): few
+ * output tiles -- token-side rows -- and a long contraction leave most of the chip idle in one pass over K, so the
+ * contraction is cut into up to 16 ranges whose partial tiles a second launch adds in range order.  Same products, another
+ * summation order than the unsplit launch. */
+size_t ft_linear_bwd_data_multi_workspace(int ntasks, int rows, int in_f, int out_f, void* stream);
+int ft_linear_bwd_data_multi_ws(int ntasks, const float* const* dy, long lddy, const float* const* w, float* dx, long lddx,
+                                int rows, int in_f, int out_f, int accumulate, int dy_tm_B, int dx_tm_B, int w_transposed,
+                                void* workspace, size_t workspace_bytes, void* stream);
 /* data gradient of the whole conv bank (backward of common_layers.py:97-102) in ONE GEMM launch; dy = [B,Tbuf,K*C]
  * gradient of the bank buffer (Tbuf = T or T+1).  Long sequences: the K members' products are accumulated in registers
  * straight into dx[B,T,Cin].  Short ones (too few output tiles to fill the chip, e.g. the prenet's B*T = 4096 rows):
