@@ -103,9 +103,19 @@ __global__ __launch_bounds__(256) void ft_lr_bwd_cols_kernel(const float* __rest
   if (f1 > Tm) f1 = Tm;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   const float* src = dy + ((long)b * dy_bs + (long)f0 * dy_ts) * C + col;
-  for (int t = f0; t < f1; ++t, src += dy_ts * C) {
-    const float4 g = *reinterpret_cast<const float4*>(src);
-    a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+  const long step = dy_ts * C;
+  // four frames in flight per lane (the rows of one token are B * C floats apart in the time-major layout: every load is
+  // an HBM access of its own), added in frame order
+  for (int t = f0; t < f1; t += 4, src += 4 * step) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g0 = *reinterpret_cast<const float4*>(src);
+    const float4 g1 = t + 1 < f1 ? *reinterpret_cast<const float4*>(src + step) : z;
+    const float4 g2 = t + 2 < f1 ? *reinterpret_cast<const float4*>(src + 2 * step) : z;
+    const float4 g3 = t + 3 < f1 ? *reinterpret_cast<const float4*>(src + 3 * step) : z;
+    a.x = (((a.x + g0.x) + g1.x) + g2.x) + g3.x;
+    a.y = (((a.y + g0.y) + g1.y) + g2.y) + g3.y;
+    a.z = (((a.z + g0.z) + g1.z) + g2.z) + g3.z;
+    a.w = (((a.w + g0.w) + g1.w) + g2.w) + g3.w;
   }
   *reinterpret_cast<float4*>((tail ? dtail + (long)b * C : dx + row * C) + col) = a;
 }
