@@ -69,4 +69,5 @@ __device__ __forceinline__ int clamp_len(const long* lens, int b, int T) {
 int ft_rnn_fwd_persistent(int G, RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream);
 // share of one XCD's CUs the persistent forward of this shape would hold (-1: it would not run persistent)
 double ft_rnn_fwd_xcd_fill(int G, int B, int T, int H, void* ws, size_t ws_bytes);
+double ft_rnn_bwd_xcd_fill(int G, int B, int T, int H, void* ws, size_t ws_bytes);
 int ft_rnn_bwd_persistent(int G, RnnBwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream);

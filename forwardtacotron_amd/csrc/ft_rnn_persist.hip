@@ -1447,7 +1447,8 @@ void admitted_launch_done(double d, hipStream_t stream) {
 // [x*per, (x+1)*per).  ALIGNED: per = whole (direction, batch group) groups, so that a group's hand-off stays inside
 // one XCD (the XCD-local protocol then applies; surplus workgroups of the larger grid exit at once); successive
 // launches start on different slots.  SPREAD: per = ceil(total / 8), groups straddle XCDs, agent-scope protocol only.
-// The aligned layout is tried first; if its (larger) per-XCD demand is not admitted, the spread one is.
+// The aligned layout is tried first; the spread one only runs when the aligned per-XCD demand exceeds a whole XCD (admit()
+// makes a launch WAIT for conflicting ones rather than refuse it, so a demand <= 1 is always taken as aligned).
 struct Layout {
   int grid, per, xcd_off, aligned;
 };
@@ -1570,6 +1571,11 @@ int fwd_persistent(RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) 
 
 template <int G, int NW, int GW, bool B3>
 int launch_bwd_persist(const RnnBwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
+  if (g_fill_probe) {
+    *g_fill_probe = xcd_demand(ft_rnn_bwd_persist_kernel<G, NW, GW, B3>, NW * 64,
+                               geo.nchunks * ft_cdiv(geo.total / geo.nchunks, 8));
+    return FT_OK;
+  }
   int grid = 0;
   const double cus = plan_launch(ft_rnn_bwd_persist_kernel<G, NW, GW, B3>, NW * 64, geo, grid, stream);
   if (cus < 0.0) return -1;
@@ -1582,6 +1588,10 @@ int launch_bwd_persist(const RnnBwdArgs& a, Geom geo, const PersistWs& p, hipStr
 
 template <int G, int NW, int NT>
 int launch_bwd_rs(const RnnBwdArgs& a, Geom geo, const PersistWs& p, hipStream_t stream) {
+  if (g_fill_probe) {
+    *g_fill_probe = xcd_demand(ft_rnn_bwd_rs_kernel<G, NW, NT>, NW * 64, geo.nchunks * ft_cdiv(geo.total / geo.nchunks, 8));
+    return FT_OK;
+  }
   int grid = 0;
   const double cus = plan_launch(ft_rnn_bwd_rs_kernel<G, NW, NT>, NW * 64, geo, grid, stream);
   if (cus < 0.0) return -1;
@@ -1688,6 +1698,20 @@ double ft_rnn_fwd_xcd_fill(int G, int B, int T, int H, void* ws, size_t ws_bytes
   return rc == FT_OK ? fill : -1.0;
 }
 
+// the same for the persistent backward of this shape (what trainer.TrainStep._predictors_first budgets with)
+double ft_rnn_bwd_xcd_fill(int G, int B, int T, int H, void* ws, size_t ws_bytes) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  RnnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.T = T; a.H = H; a.ND = 2; a.vec = H % 4 == 0;
+  double fill = -1.0;
+  g_fill_probe = &fill;
+  const int rc = G == 3 ? bwd_persistent<3>(a, ws, ws_bytes, nullptr) : bwd_persistent<4>(a, ws, ws_bytes, nullptr);
+  g_fill_probe = nullptr;
+  return rc == FT_OK ? fill : -1.0;
+}
+
 int ft_rnn_fwd_persistent(int G, RnnFwdArgs a, void* ws, size_t ws_bytes, hipStream_t stream) {
   return G == 3 ? fwd_persistent<3>(a, ws, ws_bytes, stream) : fwd_persistent<4>(a, ws, ws_bytes, stream);
 }
@@ -1706,6 +1730,17 @@ size_t ft_rnn_workspace(int gates, int B, int H) {
   size_t m = f.total_bytes > b.total_bytes ? f.total_bytes : b.total_bytes;
   return r.total_bytes > m ? r.total_bytes : m;
 }
+
+/* share of ONE XCD's CUs the persistent recurrence of this shape holds while it runs (gates 3 | 4; backward != 0: the
+ * BPTT kernel), in percent; -1: it would not run persistent.  100 = whole XCDs: no other kernel is dispatched beside it */
+int ft_rnn_xcd_fill_pct(int gates, int backward, int B, int T, int H) {
+  if ((gates != 3 && gates != 4) || B <= 0 || H <= 0) return -1;
+  void* const ws = (void*)(uintptr_t)256;            // never dereferenced by the probe
+  const double f = backward ? ft_rnn_bwd_xcd_fill(gates, B, T, H, ws, (size_t)-1)
+                            : ft_rnn_fwd_xcd_fill(gates, B, T, H, ws, (size_t)-1);
+  return f < 0.0 ? -1 : (int)(f * 100.0 + 0.5);
+}
+int ft_rnn_admit_budget_pct(void) { return (int)(0.75 * env_int("FT_RNN_ADMIT_PCT", 100) + 0.5); }
 
 int ft_rnn_set_persistent(int enabled) {
   int old = persistent_enabled() ? 1 : 0;

@@ -36,13 +36,15 @@ _models = {}
 
 
 def _rebuild(flat: torch.Tensor, cfg: str, layout: str):
-    """ForwardTacotron whose float tensors alias `flat` (cached per (address, layout))"""
-    key = (flat.data_ptr(), flat.device, cfg, layout)
+    """ForwardTacotron whose float tensors alias `flat`.  The cache holds at most TWO rebuilt models (their parameters
+    pin the flat buffer they alias: a scripted module that was deleted or moved must not stay on the GPU behind a
+    forgotten entry) and compares hashes, not the JSON strings."""
+    key = (flat.data_ptr(), flat.device, hash(cfg), hash(layout))
     m = _models.get(key)
     if m is None:
         from .model import ForwardTacotron
-        if len(_models) > 8:
-            _models.clear()
+        while len(_models) >= 2:
+            _models.pop(next(iter(_models)))          # oldest first (dicts keep insertion order)
         with torch.device('meta'):            # no allocation, no initialisation: every float tensor is re-pointed below
             m = ForwardTacotron(**json.loads(cfg))
         def owner(name):

@@ -159,11 +159,14 @@ class TrainStep:
         preds = [m.rnn for n, m in model.named_children() if n.endswith('_pred') and hasattr(m, 'rnn')]
         if post is None or not preds or not hasattr(post, 'hidden_size'):
             return False
+        # per-XCD shares of the BPTT grids, from the launcher's own occupancy arithmetic (ft_rnn_xcd_fill_pct); without a
+        # device to query (host-only tests) the formula in the docstring
         groups = 2 * ((B + 15) // 16)
 
         def demand(h):
-            return (h // 16) * ((groups + 7) // 8) / 32.0
-        return demand(post.hidden_size) + max(demand(r.hidden_size) for r in preds) <= 0.75
+            pct = H._lib.lib().ft_rnn_xcd_fill_pct(3, 1, int(B), 64, int(h)) if torch.cuda.is_available() else -1
+            return (h // 16) * ((groups + 7) // 8) / 32.0 * 100.0 if pct < 0 else pct
+        return demand(post.hidden_size) + max(demand(r.hidden_size) for r in preds) <= H._lib.lib().ft_rnn_admit_budget_pct()
 
     def _weight_packs(self) -> H.PackCache:
         """the re-laid-out weight copies of this model (hip.PackCache), rebuilt only if the flat buffer moved"""

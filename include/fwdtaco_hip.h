@@ -396,6 +396,13 @@ int ft_rnn_mode_counts(long* xcd_local_groups, long* agent_scope_groups);
 /* launches that ran in the persistent form / that did not fit the chip even alone (and ran per-step) since the library
  * loaded; ft_rnn_waited_launches: persistent launches whose stream was first made to wait for other streams' */
 int ft_rnn_counters(long* persistent_launches, long* refused_launches);
+/* Share (percent) of ONE XCD's CUs the persistent recurrence of this shape holds while it runs (gates 3 = GRU, 4 = LSTM;
+ * backward != 0: the BPTT kernel); -1: it would not run persistent.  Two persistent launches on different streams are
+ * co-resident while their shares add up to at most ft_rnn_admit_budget_pct(); a launch at 100 fills whole XCDs, and no
+ * other kernel is dispatched anywhere while it is resident (the dispatcher deals workgroups to the XCDs round-robin and
+ * waits at the first full one). */
+int ft_rnn_xcd_fill_pct(int gates, int backward, int B, int T, int H);
+int ft_rnn_admit_budget_pct(void);
 int ft_rnn_waited_launches(void);
 int ft_gru_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
                float* out, float* gates, int B, int T, int H, void* workspace, size_t workspace_bytes,

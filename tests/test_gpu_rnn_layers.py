@@ -166,3 +166,17 @@ def test_regulated_lstm_equals_regulator_then_lstm(B, Tx, I, Hh, packed, zero_du
     for k in a[2]:
         ref = float(a[2][k].abs().max())
         assert float((a[2][k] - b[2][k]).abs().max()) <= 2e-5 * max(1.0, ref), k
+
+
+def test_xcd_fill_of_the_persistent_grids():
+    """ft_rnn_xcd_fill_pct: the 512-wide LSTM holds every CU of its XCDs (nothing can be launched beside it -- the layer
+    forward must not try to), the 256-wide GRU half of them; shapes that do not run persistent report -1"""
+    from forwardtacotron_amd import _lib
+    L = _lib.lib()
+    assert L.ft_rnn_xcd_fill_pct(4, 0, 32, 841, 512) == 100
+    assert L.ft_rnn_xcd_fill_pct(4, 1, 32, 841, 512) == 100
+    assert L.ft_rnn_xcd_fill_pct(3, 0, 32, 841, 256) == 50
+    assert L.ft_rnn_xcd_fill_pct(3, 1, 32, 841, 256) == 50
+    assert L.ft_rnn_xcd_fill_pct(3, 1, 32, 128, 64) <= 25
+    assert L.ft_rnn_xcd_fill_pct(3, 0, 4, 12, 12) == -1          # H % 16 != 0: per-step kernels
+    assert 0 < L.ft_rnn_admit_budget_pct() <= 75
