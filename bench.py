@@ -124,7 +124,7 @@ def family_rooflines(recs, steps, batch, step_ms, lr_iso_ms=None):
     side = {'ms': 0.0, 'flop': 0.0, 'dep_steps': 0, 'launches': 0}
     lr_ms, lr_bytes = 0.0, 0.0
     for name, info, ms in recs:
-        if name == 'lr_expand':
+        if name in ('lr_expand', 'lr_expand_tm'):
             lr_ms += ms
             lr_bytes += info['bytes']
             continue
@@ -149,7 +149,9 @@ def family_rooflines(recs, steps, batch, step_ms, lr_iso_ms=None):
     if lr_ms > 0:
         ms = lr_iso_ms if lr_iso_ms else lr_ms / steps
         tbs = lr_bytes / steps / (ms * 1e-3) / 1e12
-        out.append({'family': 'LengthRegulator expand (ft_lr_expand_kernel)', 'bound': 'hbm',
+        out.append({'family': 'LengthRegulator expand (ft_lr_expand_kernel; in the regulated-LSTM path it carries the '
+                              'per-token input projection, 4096 floats per row, into the recurrence\'s time-major layout)',
+                    'bound': 'hbm',
                     'launch_ms': round(ms, 4), 'timing': '50 launches back to back between one event pair' if lr_iso_ms
                     else 'event pair around the in-step launch', 'in_step_event_pair_ms': round(lr_ms / steps, 4),
                     'bytes_per_launch': lr_bytes / steps,
@@ -181,23 +183,26 @@ def install_family_probes(probes, batch):
         x, cum, Tm = a[0], a[1], a[2]
         Bq, Tx, C = x.shape
         probes.lr_args = (x, cum, Tm)            # for the back-to-back timing below (the operands of the last step)
+        probes.lr_fn = 'lr_expand_tm' if len(a) > 3 or k else 'lr_expand'
         # algorithmic bytes: one 4*C-byte row read per valid token + one written per output frame (B x Tm)
         return {'bytes': 4.0 * C * (float(batch['x_len'].sum()) + Bq * Tm)}
 
     probes.wrap('lr_expand', lr)
+    probes.wrap('lr_expand_tm', lr)          # (x, cum, Tm, pad_row, want_src=...)
 
 
-def lr_back_to_back_ms(hip_mod, args, n=50):
+def lr_back_to_back_ms(hip_mod, args, n=50, fn='lr_expand'):
     """An event pair around ONE 12-us launch mostly measures the events; n launches back to back between one pair give the
     kernel's own time (+ the ~1.5 us dependent-launch boundary).  The output tensor is re-allocated per call by the
     wrapper (caching allocator: no device work)."""
     x, cum, Tm = args
+    expand = getattr(hip_mod, fn)
     for _ in range(3):
-        hip_mod.lr_expand(x, cum, Tm)
+        expand(x, cum, Tm)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        hip_mod.lr_expand(x, cum, Tm)
+        expand(x, cum, Tm)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
@@ -230,7 +235,7 @@ def wgrad_family(hip_mod, device, n=20):
     ach = flops / (ms * 1e-3) / 1e12
     b3 = os.environ.get('FT_GEMM_B3', '1') != '0'
     piped = os.environ.get('FT_GEMM_TN_PIPE', '1') != '0'
-    rec = {'family': 'weight-gradient GEMM (decoder LSTM W_ih, one direction: 2048 x 512 over 26912 time-major rows)',
+    rec = {'family': 'weight-gradient GEMM (decoder LSTM W_hh, one direction: 2048 x 512 over 26912 time-major rows)',
            'bound': 'mfma', 'kernels': ('ft_gemm_tn_b3p_kernel' if piped else 'ft_gemm_tn_b3_kernel') if b3 else 'ft_gemm_tn_kernel',
            'launch_ms': round(ms, 4), 'timing': f'{n} launches back to back between one event pair (incl. the ordered slab sum)',
            'flops_per_launch': flops, 'achieved': round(ach, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -393,7 +398,8 @@ def main():
                 one_step()
             torch.cuda.synchronize()
             fp.remove()
-            lr_iso = lr_back_to_back_ms(_hip, fp.lr_args) if getattr(fp, 'lr_args', None) else None
+            lr_iso = (lr_back_to_back_ms(_hip, fp.lr_args, fn=getattr(fp, 'lr_fn', 'lr_expand'))
+                      if getattr(fp, 'lr_args', None) else None)
             fam = family_rooflines(fp.results(), args.family_steps, batch, elapsed / args.steps * 1e3, lr_iso)
             fam.append(wgrad_family(_hip, device))
         flag = torch.tensor([ok], device=device)
