@@ -4,6 +4,8 @@
 // allocation, argument marshalling, autograd bookkeeping: ~15 us each) it was bound by the host at 15 ms.
 #include <mutex>
 
+#include <stdlib.h>
+
 #include "ft_common.h"
 #include "fwdtaco_hip.h"
 
@@ -139,20 +141,69 @@ int ft_fft_blocks_bwd(const FtFFTBlock* blocks, const FtFFTBlockGrads* grads, in
     sums_workspace_bytes = wgrad_workspace_bytes;
     sums_stream = wgrad_stream;               // one workspace: one stream
   }
-  for (int i = n - 1; i >= 0; --i) {
-    FT_TRY(block_bwd_data(blocks[i], grads[i], workspace, workspace_bytes, stream));
-    if (fork) {
-      bool ok = hipEventRecord(ev, (hipStream_t)stream) == hipSuccess;
-      if (wgrad_stream != stream) ok = ok && hipStreamWaitEvent((hipStream_t)wgrad_stream, ev, 0) == hipSuccess;
-      if (sums_stream != stream && sums_stream != wgrad_stream)
-        ok = ok && hipStreamWaitEvent((hipStream_t)sums_stream, ev, 0) == hipSuccess;
-      if (!ok) {
-        ft_set_error("fft_blocks_bwd: stream fork failed");
-        return FT_ERR_HIP;
-      }
+  // the side streams follow the main stream's position: every weight gradient / column sum is issued as soon as the data
+  // path has produced its operand (one fork per stage, four per block -- a fork per BLOCK left the weight-gradient stream
+  // 1.9 ms behind the main stream at the end of a 15 ms step)
+  auto follow = [&]() -> int {
+    if (!fork) return FT_OK;
+    bool ok = hipEventRecord(ev, (hipStream_t)stream) == hipSuccess;
+    if (wgrad_stream != stream) ok = ok && hipStreamWaitEvent((hipStream_t)wgrad_stream, ev, 0) == hipSuccess;
+    if (sums_stream != stream && sums_stream != wgrad_stream)
+      ok = ok && hipStreamWaitEvent((hipStream_t)sums_stream, ev, 0) == hipSuccess;
+    if (!ok) {
+      ft_set_error("fft_blocks_bwd: stream fork failed");
+      return FT_ERR_HIP;
     }
-    FT_TRY(block_bwd_weights(blocks[i], grads[i], wgrad_workspace, wgrad_workspace_bytes, wgrad_stream));
-    FT_TRY(block_bwd_sums(blocks[i], grads[i], sums_workspace, sums_workspace_bytes, sums_stream));
+    return FT_OK;
+  };
+  static const bool per_stage = [] {                 // FT_FFT_FORK_PER_BLOCK=1: one fork per block (A/B knob)
+    const char* e = getenv("FT_FFT_FORK_PER_BLOCK");
+    return !(e && e[0] == '1');
+  }();
+  for (int i = n - 1; i >= 0; --i) {
+    const FtFFTBlock& b = blocks[i];
+    const FtFFTBlockGrads& g = grads[i];
+    if (!per_stage) {
+      FT_TRY(block_bwd_data(b, g, workspace, workspace_bytes, stream));
+      FT_TRY(follow());
+      FT_TRY(block_bwd_weights(b, g, wgrad_workspace, wgrad_workspace_bytes, wgrad_stream));
+      FT_TRY(block_bwd_sums(b, g, sums_workspace, sums_workspace_bytes, sums_stream));
+      continue;
+    }
+    const int rows = b.B * b.T, d = b.d, f = b.dfft;
+    const int hd = d / b.nheads;
+    const float scale = 1.0f / sqrtf((float)hd);
+    void* const st = stream;
+    void* const wst = wgrad_stream;
+    void* const sst = sums_stream;
+    // (the same launches with the same operands as block_bwd_data / _weights / _sums, interleaved)
+    FT_TRY(ft_layernorm_bwd(g.dy2, b.s2, b.n2_g, b.mean2, b.rstd2, g.d_y1, g.t2, g.d_h2, rows, d, b.p_drop, b.seed_ln2, st));
+    FT_TRY(follow());
+    FT_TRY(ft_conv1d_bwd_weight(g.d_h2, d, b.h1, f, g.g_c2_w, b.B, b.T, f, d, b.k2, b.T, b.T, wgrad_workspace,
+                                wgrad_workspace_bytes, wst));
+    FT_TRY(ft_colsum2(g.t2, g.dy2, d, g.g_n2_g, g.g_n2_b, rows, d, sums_workspace, sums_workspace_bytes, sst));
+    FT_TRY(ft_colsum(g.d_h2, d, g.g_c2_b, rows, d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    FT_TRY(ft_conv1d_bwd_data_relu(g.d_h2, d, b.c2_wpt, b.h1, g.g_h1, f, b.B, b.T, f, d, b.k2, 1, st));
+    FT_TRY(follow());
+    FT_TRY(ft_conv1d_bwd_weight(g.g_h1, f, b.y1, d, g.g_c1_w, b.B, b.T, d, f, b.k1, b.T, b.T, wgrad_workspace,
+                                wgrad_workspace_bytes, wst));
+    FT_TRY(ft_colsum(g.g_h1, f, g.g_c1_b, rows, f, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    FT_TRY(ft_conv1d_bwd_data(g.g_h1, f, b.c1_wpt, g.d_y1, d, b.B, b.T, d, f, b.k1, b.T, b.T, 1, 1, st));     // += residual path
+    FT_TRY(ft_layernorm_bwd(g.d_y1, b.s1, b.n1_g, b.mean1, b.rstd1, g.d_h, g.t1, g.d_sa, rows, d, b.p_drop, b.seed_ln1, st));
+    FT_TRY(follow());
+    FT_TRY(ft_linear_bwd_weight(g.d_sa, d, b.att, d, g.g_out_w, rows, d, d, 1, rows, 0, 0, 0, 0, wgrad_workspace,
+                                wgrad_workspace_bytes, wst));
+    FT_TRY(ft_colsum2(g.t1, g.d_y1, d, g.g_n1_g, g.g_n1_b, rows, d, sums_workspace, sums_workspace_bytes, sst));
+    FT_TRY(ft_colsum(g.d_sa, d, g.g_out_b, rows, d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    FT_TRY(ft_linear_bwd_data(g.d_sa, d, b.out_wT, g.datt, d, rows, d, d, 0, 0, 0, 1, st));
+    FT_TRY(ft_attn_bwd(b.qkv, b.att, g.datt, b.key_pad, b.lse2, g.dqkv, b.B, b.T, b.nheads, hd, scale, b.p_drop, b.seed_attn,
+                       workspace, workspace_bytes, st));
+    FT_TRY(follow());
+    FT_TRY(ft_linear_bwd_weight(g.dqkv, 3 * d, b.x, d, g.g_in_w, rows, d, 3 * d, 1, rows, 0, 0, 0, 0, wgrad_workspace,
+                                wgrad_workspace_bytes, wst));
+    FT_TRY(ft_colsum(g.dqkv, 3 * d, g.g_in_b, rows, 3 * d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    FT_TRY(ft_linear_bwd_data(g.dqkv, 3 * d, b.in_wT, g.d_h, d, rows, d, 3 * d, 1, 0, 0, 1, st));
+    FT_REQUIRE(g.dx == g.d_h, "fft_blocks_bwd: dx must alias d_h (the in-projection's data gradient accumulates into it)");
   }
   return FT_OK;
 }
