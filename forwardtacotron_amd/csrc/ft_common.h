@@ -52,12 +52,20 @@ __device__ __forceinline__ double ft_wave_sum_d(double v) {
 }
 
 // counter-based dropout mask (ft_dropout and the kernels that fuse it): element i of a tensor is kept iff u(seed, i) >= p;
-// the backward re-derives the same mask from the seed, so no mask tensor is stored
-__device__ __forceinline__ uint32_t ft_hash32(uint64_t v) {
-  v ^= v >> 33; v *= 0xff51afd7ed558ccdULL; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ULL; v ^= v >> 33;
-  return (uint32_t)v;
+// the backward re-derives the same mask from the seed, so no mask tensor is stored.  32-bit mixing (three multiplies:
+// the attention kernels draw one decision per score element, forward and twice in the backward -- the 64-bit finalizer
+// used until round 3 was 19 % of the fused attention forward); index and seed enter in full.
+__device__ __forceinline__ uint32_t ft_hash32(uint64_t seed, uint64_t i) {
+  uint32_t h = (uint32_t)i ^ ((uint32_t)(i >> 32) * 0x9E3779B1u);
+  h = (h ^ (uint32_t)seed) * 0x85EBCA6Bu;
+  h ^= h >> 15;
+  h = (h + (uint32_t)(seed >> 32)) * 0xC2B2AE35u;
+  h ^= h >> 13;
+  h *= 0x27D4EB2Fu;
+  h ^= h >> 16;
+  return h;
 }
 __device__ __forceinline__ bool ft_dropout_keep(uint64_t seed, long i, float p) {
-  const uint32_t h = ft_hash32(seed * 0x9e3779b97f4a7c15ULL + (uint64_t)i);
+  const uint32_t h = ft_hash32(seed, (uint64_t)i);
   return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
 }
