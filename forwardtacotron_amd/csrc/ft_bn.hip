@@ -8,6 +8,8 @@
 //
 // All reductions are two-stage (per-block double partials -> ordered finalize), so results are bitwise
 // reproducible run to run.  These kernels are HBM-bound: one pass over the activation per stage.
+#include <string.h>
+
 #include "ft_common.h"
 
 namespace {
@@ -492,6 +494,80 @@ bool all16(P... ptrs) {
   return (((uintptr_t)(const void*)ptrs % 16 == 0) && ...);
 }
 
+// ---- several column sums over matrices with the SAME row count in one partial + one finalize launch -----------------
+// (a FastPitch step computed 255 bias / LayerNorm gradients as 255 pairs of 5-8 us launches: 1.7 ms of kernel time).
+// Every task keeps the chunking and the summation order of its stand-alone ft_colsum call: bit-identical results.
+constexpr int CSB_MAX = 16;
+struct ColsumBatch {
+  const float* x[CSB_MAX];
+  float* out[CSB_MAX];
+  long ld[CSB_MAX], ws_off[CSB_MAX];       // ws_off in doubles
+  int C[CSB_MAX], nchunks[CSB_MAX], rpc[CSB_MAX];
+  int tile64[CSB_MAX + 1], tile32[CSB_MAX + 1];   // prefix sums of the tasks' 64- / 32-column tiles
+  int n;
+  long rows;
+};
+
+__global__ __launch_bounds__(256) void ft_colsum_batch_partial_kernel(ColsumBatch b, double* __restrict__ ws) {
+  int t = 0;
+  while (t + 1 < b.n && (int)blockIdx.x >= b.tile64[t + 1]) ++t;
+  if ((int)blockIdx.y >= b.nchunks[t]) return;
+  const float* __restrict__ x = b.x[t];
+  const long ldx = b.ld[t];
+  const int C = b.C[t];
+  double* __restrict__ partial = ws + b.ws_off[t];
+  __shared__ double red[16][65];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int tile = blockIdx.x - b.tile64[t];
+  const int c = tile * 64 + cq * 4;
+  const long r0 = (long)blockIdx.y * b.rpc[t];
+  long r1 = r0 + b.rpc[t];
+  if (r1 > b.rows) r1 = b.rows;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C) {
+    for (long r = r0 + rl; r < r1; r += 64) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long rr = r + 16 * u;
+        v[u] = rr < r1 ? *reinterpret_cast<const float4*>(x + rr * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[0] += (double)v[u].x;
+        s[1] += (double)v[u].y;
+        s[2] += (double)v[u].z;
+        s[3] += (double)v[u].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cq * 4 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = tile * 64 + threadIdx.x;
+    if (cc < C) {
+      double a = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += red[i][threadIdx.x];
+      partial[((long)blockIdx.y * C + cc) * 2] = a;
+      partial[((long)blockIdx.y * C + cc) * 2 + 1] = 0.0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ft_colsum_batch_finalize_kernel(ColsumBatch b, const double* __restrict__ ws) {
+  int t = 0;
+  while (t + 1 < b.n && (int)blockIdx.x >= b.tile32[t + 1]) ++t;
+  __shared__ double sh[32][FIN_PARTS][2];
+  const int slot = threadIdx.x >> 3, part = threadIdx.x & 7;
+  const int c = (blockIdx.x - b.tile32[t]) * 32 + slot;
+  double s0, s1;
+  sum_partials(ws + b.ws_off[t], b.nchunks[t], b.C[t], c, part, sh, slot, s0, s1);
+  if (part != 0 || c >= b.C[t]) return;
+  b.out[t][c] = (float)s0;
+}
+
 struct ChunkPlan {
   int nchunks, rows_per_chunk;
 };
@@ -712,6 +788,51 @@ int ft_colsum2(const float* x0, const float* x1, long ldx, float* out0, float* o
   hipLaunchKernelGGL(ft_col_finalize_kernel, dim3(ft_cdiv(C, 32)), dim3(256), 0, s, (const double*)workspace,
                      p.nchunks, C, out0, out1, 1.0f, 0);
   return ft_check_launch("colsum2");
+}
+
+size_t ft_colsum_batch_workspace(int n, const int* C, int rows) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) total += ft_colsum_workspace(rows, C[i]);
+  return total;
+}
+
+// out[i][c] = sum over rows of x[i][r * ld[i] + c], i < n <= 16, all with `rows` rows: one partial and one finalize launch
+// for the lot, each sum bit-identical to its own ft_colsum call
+int ft_colsum_batch(int n, const float* const* x, const long* ld, float* const* out, const int* C, int rows,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  FT_REQUIRE(n >= 0 && n <= CSB_MAX && rows >= 0, "colsum_batch: n = %d (max %d), rows = %d", n, CSB_MAX, rows);
+  if (n == 0) return FT_OK;
+  bool vec = rows > 0;
+  for (int i = 0; i < n; ++i)
+    vec = vec && C[i] > 0 && C[i] % 4 == 0 && ld[i] % 4 == 0 && ((uintptr_t)x[i]) % 16 == 0;
+  if (!vec) {                   // rare shapes: one call each
+    for (int i = 0; i < n; ++i) {
+      const int rc = ft_colsum(x[i], ld[i], out[i], rows, C[i], 1.0f, 0, workspace, workspace_bytes, stream);
+      if (rc) return rc;
+    }
+    return FT_OK;
+  }
+  FT_REQUIRE(workspace && workspace_bytes >= ft_colsum_batch_workspace(n, C, rows), "colsum_batch: workspace too small");
+  ColsumBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n;
+  b.rows = rows;
+  long off = 0;
+  int maxchunks = 1;
+  for (int i = 0; i < n; ++i) {
+    const ChunkPlan p = plan_chunks(rows, C[i]);
+    b.x[i] = x[i]; b.out[i] = out[i]; b.ld[i] = ld[i]; b.C[i] = C[i];
+    b.nchunks[i] = p.nchunks; b.rpc[i] = p.rows_per_chunk;
+    b.ws_off[i] = off;
+    off += (long)(ft_colsum_workspace(rows, C[i]) / sizeof(double));
+    b.tile64[i + 1] = b.tile64[i] + ft_cdiv(C[i], 64);
+    b.tile32[i + 1] = b.tile32[i] + ft_cdiv(C[i], 32);
+    if (p.nchunks > maxchunks) maxchunks = p.nchunks;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ft_colsum_batch_partial_kernel, dim3(b.tile64[n], maxchunks), dim3(256), 0, s, b, (double*)workspace);
+  hipLaunchKernelGGL(ft_colsum_batch_finalize_kernel, dim3(b.tile32[n]), dim3(256), 0, s, b, (const double*)workspace);
+  return ft_check_launch("colsum_batch");
 }
 
 }  // extern "C"

@@ -89,6 +89,16 @@ int block_bwd_sums(const FtFFTBlock& b, const FtFFTBlockGrads& g, void* ws, size
   return FT_OK;
 }
 
+// the same eight sums as block_bwd_sums in ONE pair of launches (ft_colsum_batch), issued once the block's data path is done
+int block_bwd_sums_batched(const FtFFTBlock& b, const FtFFTBlockGrads& g, void* ws, size_t wsb, void* st) {
+  const int rows = b.B * b.T, d = b.d, f = b.dfft;
+  const float* x[8] = {g.t2, g.dy2, g.d_h2, g.g_h1, g.t1, g.d_y1, g.d_sa, g.dqkv};
+  const long ld[8] = {d, d, d, f, d, d, d, 3L * d};
+  float* out[8] = {g.g_n2_g, g.g_n2_b, g.g_c2_b, g.g_c1_b, g.g_n1_g, g.g_n1_b, g.g_out_b, g.g_in_b};
+  const int C[8] = {d, d, d, f, d, d, d, 3 * d};
+  return ft_colsum_batch(8, x, ld, out, C, rows, ws, wsb, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -115,6 +125,11 @@ size_t ft_fft_block_wgrad_workspace(int B, int T, int d, int dfft, int k1, int k
 
 size_t ft_fft_block_sums_workspace(int B, int T, int d, int dfft) {
   const int rows = B * T;
+  {
+    const int C[8] = {d, d, d, dfft, d, d, d, 3 * d};
+    const size_t batched = ft_colsum_batch_workspace(8, C, rows);
+    if (batched > 0) return batched;            // (covers the per-sum calls too: it is their sum)
+  }
   size_t m = ft_colsum_workspace(rows, 3 * d);
   auto up = [&](size_t v) { if (v > m) m = v; };
   up(ft_colsum_workspace(rows, dfft));
@@ -160,6 +175,10 @@ int ft_fft_blocks_bwd(const FtFFTBlock* blocks, const FtFFTBlockGrads* grads, in
     const char* e = getenv("FT_FFT_FORK_PER_BLOCK");
     return !(e && e[0] == '1');
   }();
+  static const bool batch_sums = [] {                // FT_FFT_BATCH_SUMS=0: eight column-sum calls per block (A/B knob)
+    const char* e = getenv("FT_FFT_BATCH_SUMS");
+    return !(e && e[0] == '0');
+  }();
   for (int i = n - 1; i >= 0; --i) {
     const FtFFTBlock& b = blocks[i];
     const FtFFTBlockGrads& g = grads[i];
@@ -181,27 +200,32 @@ int ft_fft_blocks_bwd(const FtFFTBlock* blocks, const FtFFTBlockGrads* grads, in
     FT_TRY(follow());
     FT_TRY(ft_conv1d_bwd_weight(g.d_h2, d, b.h1, f, g.g_c2_w, b.B, b.T, f, d, b.k2, b.T, b.T, wgrad_workspace,
                                 wgrad_workspace_bytes, wst));
-    FT_TRY(ft_colsum2(g.t2, g.dy2, d, g.g_n2_g, g.g_n2_b, rows, d, sums_workspace, sums_workspace_bytes, sst));
-    FT_TRY(ft_colsum(g.d_h2, d, g.g_c2_b, rows, d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    if (!batch_sums) {
+      FT_TRY(ft_colsum2(g.t2, g.dy2, d, g.g_n2_g, g.g_n2_b, rows, d, sums_workspace, sums_workspace_bytes, sst));
+      FT_TRY(ft_colsum(g.d_h2, d, g.g_c2_b, rows, d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    }
     FT_TRY(ft_conv1d_bwd_data_relu(g.d_h2, d, b.c2_wpt, b.h1, g.g_h1, f, b.B, b.T, f, d, b.k2, 1, st));
     FT_TRY(follow());
     FT_TRY(ft_conv1d_bwd_weight(g.g_h1, f, b.y1, d, g.g_c1_w, b.B, b.T, d, f, b.k1, b.T, b.T, wgrad_workspace,
                                 wgrad_workspace_bytes, wst));
-    FT_TRY(ft_colsum(g.g_h1, f, g.g_c1_b, rows, f, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    if (!batch_sums) FT_TRY(ft_colsum(g.g_h1, f, g.g_c1_b, rows, f, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
     FT_TRY(ft_conv1d_bwd_data(g.g_h1, f, b.c1_wpt, g.d_y1, d, b.B, b.T, d, f, b.k1, b.T, b.T, 1, 1, st));     // += residual path
     FT_TRY(ft_layernorm_bwd(g.d_y1, b.s1, b.n1_g, b.mean1, b.rstd1, g.d_h, g.t1, g.d_sa, rows, d, b.p_drop, b.seed_ln1, st));
     FT_TRY(follow());
     FT_TRY(ft_linear_bwd_weight(g.d_sa, d, b.att, d, g.g_out_w, rows, d, d, 1, rows, 0, 0, 0, 0, wgrad_workspace,
                                 wgrad_workspace_bytes, wst));
-    FT_TRY(ft_colsum2(g.t1, g.d_y1, d, g.g_n1_g, g.g_n1_b, rows, d, sums_workspace, sums_workspace_bytes, sst));
-    FT_TRY(ft_colsum(g.d_sa, d, g.g_out_b, rows, d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    if (!batch_sums) {
+      FT_TRY(ft_colsum2(g.t1, g.d_y1, d, g.g_n1_g, g.g_n1_b, rows, d, sums_workspace, sums_workspace_bytes, sst));
+      FT_TRY(ft_colsum(g.d_sa, d, g.g_out_b, rows, d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    }
     FT_TRY(ft_linear_bwd_data(g.d_sa, d, b.out_wT, g.datt, d, rows, d, d, 0, 0, 0, 1, st));
     FT_TRY(ft_attn_bwd(b.qkv, b.att, g.datt, b.key_pad, b.lse2, g.dqkv, b.B, b.T, b.nheads, hd, scale, b.p_drop, b.seed_attn,
                        workspace, workspace_bytes, st));
     FT_TRY(follow());
     FT_TRY(ft_linear_bwd_weight(g.dqkv, 3 * d, b.x, d, g.g_in_w, rows, d, 3 * d, 1, rows, 0, 0, 0, 0, wgrad_workspace,
                                 wgrad_workspace_bytes, wst));
-    FT_TRY(ft_colsum(g.dqkv, 3 * d, g.g_in_b, rows, 3 * d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
+    if (batch_sums) FT_TRY(block_bwd_sums_batched(b, g, sums_workspace, sums_workspace_bytes, sst));
+    else FT_TRY(ft_colsum(g.dqkv, 3 * d, g.g_in_b, rows, 3 * d, 1.0f, 0, sums_workspace, sums_workspace_bytes, sst));
     FT_TRY(ft_linear_bwd_data(g.dqkv, 3 * d, b.in_wT, g.d_h, d, rows, d, 3 * d, 1, 0, 0, 1, st));
     FT_REQUIRE(g.dx == g.d_h, "fft_blocks_bwd: dx must alias d_h (the in-projection's data gradient accumulates into it)");
   }

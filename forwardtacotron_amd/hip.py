@@ -667,6 +667,24 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def colsum_batch(xs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """column sums of up to 16 matrices with the same row count in one partial + one finalize launch (each bit-identical
+    to colsum of that matrix)"""
+    rows = xs[0].numel() // xs[0].shape[-1]
+    for x in xs:
+        _chk(x, 'x')
+        assert x.numel() // x.shape[-1] == rows
+    n = len(xs)
+    outs = [torch.empty(x.shape[-1], device=x.device, dtype=x.dtype) for x in xs]
+    Cs = (ctypes.c_int * n)(*[int(x.shape[-1]) for x in xs])
+    lds = (ctypes.c_long * n)(*[int(x.shape[-1]) for x in xs])
+    nbytes = _lib.lib().ft_colsum_batch_workspace(n, ctypes.cast(Cs, c_void_p), rows)
+    ws = workspace(max(int(nbytes), 16), xs[0].device)
+    _lib.call('ft_colsum_batch', n, ctypes.cast(_ptr_array(list(xs)), c_void_p), ctypes.cast(lds, c_void_p),
+              ctypes.cast(_ptr_array(outs), c_void_p), ctypes.cast(Cs, c_void_p), rows, _p(ws), ws.numel(), _stream())
+    return outs
+
+
 # ---------------------------------------------------------------------------------------------------
 # element-wise
 # ---------------------------------------------------------------------------------------------------

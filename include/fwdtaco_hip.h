@@ -281,6 +281,11 @@ int ft_colsum(const float* x, long ldx, float* out, int rows, int C, float scale
  * dgamma = colsum(dy * xhat), dbeta = colsum(dy) */
 int ft_colsum2(const float* x0, const float* x1, long ldx, float* out0, float* out1, int rows, int C, void* workspace,
                size_t workspace_bytes, void* stream);
+/* n <= 16 column sums over matrices with the same row count in ONE partial + ONE finalize launch: out[i][c] = sum_r
+ * x[i][r * ld[i] + c].  Every sum keeps the chunking and summation order of its own ft_colsum call (bit-identical). */
+size_t ft_colsum_batch_workspace(int n, const int* C, int rows);
+int ft_colsum_batch(int n, const float* const* x, const long* ld, float* const* out, const int* C, int rows,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- F.dropout (forward_tacotron.py:35 ; common_layers.py:106,110) and scalar scale (x/alpha, :39) ----- */
 /* out = keep ? x/(1-p) : 0 with keep(i) = hash(seed,i) >= p; calling it on the gradient with the same seed

@@ -555,3 +555,20 @@ def test_highway_stack_gates_in_the_gemm_epilogues(H, rows, C, layers, monkeypat
     assert maxdiff(res['1'][1], res['0'][1]) <= 1e-6 * max(1.0, float(xo.grad.abs().max()))
     for a, b in zip(res['1'][2], res['0'][2]):
         assert maxdiff(a, b) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+def test_batched_column_sums_are_bit_identical_to_one_call_each(H):
+    """ft_colsum_batch: one partial + one finalize launch for up to 16 matrices of equal row count, every sum with the
+    chunking and order of its own ft_colsum call (the FFT blocks' eight bias / LayerNorm gradients per block)"""
+    g = torch.Generator().manual_seed(5)
+    for rows, widths in ((26912, (256, 256, 256, 1024, 256, 256, 256, 768)), (4096, (128, 128, 384)), (37, (64, 4, 260)),
+                         (1, (8,))):
+        xs = [torch.randn(rows, c, generator=g).cuda() for c in widths]
+        got = H.colsum_batch(xs)
+        for x, s in zip(xs, got):
+            assert torch.equal(s, H.colsum(x))
+            assert maxdiff(s.cpu(), x.double().sum(0).cpu()) <= 1e-5 * max(1.0, float(x.abs().sum(0).max()))
+    # widths that cannot take the 16-byte path fall back to one call each
+    xs = [torch.randn(50, c, generator=g).cuda() for c in (6, 64)]
+    for x, s in zip(xs, H.colsum_batch(xs)):
+        assert torch.equal(s, H.colsum(x))
