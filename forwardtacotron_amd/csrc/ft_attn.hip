@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : 2) void ft_attn_fwd_kernel(const
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float p = exp2f(x[kt][e] - msafe);
+        float p = __builtin_amdgcn_exp2f(x[kt][e] - msafe);      // v_exp_f32 (the ocml form was 7 % of the kernel)
         lsum += p;
         if (drop) {
           const long idx = ((long)inst * T + myq) * T + (kb * KB + 32 * kt + crow(e, hf));
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, HD > 64 ? 1 : 2) void ft_attn_bwd_dq_kernel(co
       for (int e = 0; e < 16; ++e) {
         const int kk = 32 * kt + crow(e, hf);
         const bool masked = (pm >> kk) & 1ull;
-        const float p = masked ? 0.f : exp2f(x[e] * c - L);
+        const float p = masked ? 0.f : __builtin_amdgcn_exp2f(x[e] * c - L);
         float g = y[e];
         if (drop) {
           const long idx = ((long)inst * T + myq) * T + (kb * KB + kk);
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void ft_attn_bwd_dkv_kernel(const float* __
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int qq = 32 * qt + crow(e, hf);                       // query (tile row) of this register
-        const float p = kmask ? 0.f : exp2f(x[e] * c - sL[qq]);
+        const float p = kmask ? 0.f : __builtin_amdgcn_exp2f(x[e] * c - sL[qq]);
         float keepf = 1.f;
         if (drop) {
           const long idx = ((long)inst * T + (qb * KB + qq)) * T + myk;
