@@ -357,9 +357,12 @@ int ft_conv_bank_fwd(const float* x, long ldx, const float* wp_all, const float*
   long woff = 0;
   for (int i = 0; i < K; ++i) {
     int k = i + 1;
-    conv_fwd_task(b.t[i], x, ldx, wp_all + woff, ybank + (long)i * C, (long)K * C, B, T, Cin, C, k, Tout, relu);
-    b.t[i].scale = scale ? scale + (long)i * C : nullptr;
-    b.t[i].shift = shift ? shift + (long)i * C : nullptr;
+    // member i (k taps) is task K - 1 - i: workgroups are dispatched in task order, and the members with the most taps
+    // should start first (longest-processing-time order: the launch used to end on a tail of the K-tap member's tiles)
+    FtGemmTask& t = b.t[K - 1 - i];
+    conv_fwd_task(t, x, ldx, wp_all + woff, ybank + (long)i * C, (long)K * C, B, T, Cin, C, k, Tout, relu);
+    t.scale = scale ? scale + (long)i * C : nullptr;
+    t.shift = shift ? shift + (long)i * C : nullptr;
     woff += (long)k * C * Cin;
   }
   return ft_launch_gemm_rows(&b, K, false, (hipStream_t)stream);
@@ -469,11 +472,12 @@ int ft_conv_bank_fwd_stats(const float* x, long ldx, const float* wp_all, float*
   long woff = 0;
   for (int i = 0; i < K; ++i) {
     int k = i + 1;
-    conv_fwd_task(b.t[i], x, ldx, wp_all + woff, ybank + (long)i * C, (long)K * C, B, T, Cin, C, k, Tout, relu);
-    b.t[i].stat = stats_in_epilogue() ? partial : nullptr;
-    b.t[i].stat_ld = K * C;
-    b.t[i].stat_col0 = i * C;
-    b.t[i].stat_tvalid = (k & 1) ? T : T + 1;           // BatchNorm of an odd-k member sees T rows
+    FtGemmTask& t = b.t[K - 1 - i];                   // most taps first (see ft_conv_bank_fwd)
+    conv_fwd_task(t, x, ldx, wp_all + woff, ybank + (long)i * C, (long)K * C, B, T, Cin, C, k, Tout, relu);
+    t.stat = stats_in_epilogue() ? partial : nullptr;
+    t.stat_ld = K * C;
+    t.stat_col0 = i * C;
+    t.stat_tvalid = (k & 1) ? T : T + 1;              // BatchNorm of an odd-k member sees T rows
     woff += (long)k * C * Cin;
   }
   int rc = ft_launch_gemm_rows(&b, K, false, (hipStream_t)stream);
