@@ -179,16 +179,6 @@ def install_family_probes(probes, batch):
     probes.wrap('lstm_fwd', rnn(4, True))
     probes.wrap('lstm_bwd', rnn(4, True))
 
-    def regulated(a, k):
-        # lstm_fwd_regulated(P [B,Tx,8H], cum, Tm, pad_row, whh_f, whh_r, bhh_f, bhh_r, lens, H, save_gates): the decoder
-        # LSTM's forward in the regulated path (+ the row-map index kernel, or the expansion where no row map applies)
-        H = int(a[9]) if len(a) > 9 else int(k['H'])
-        lens = a[8] if len(a) > 8 else k.get('lens')
-        valid = lens_sum if lens is not None else float(a[0].shape[0] * int(a[2]))
-        return {'T': int(a[2]), 'H': H, 'flop': 2.0 * valid * 2 * 4 * H * H}
-
-    probes.wrap('lstm_fwd_regulated', regulated)
-
     def lr(a, k):
         x, cum, Tm = a[0], a[1], a[2]
         Bq, Tx, C = x.shape
@@ -199,22 +189,6 @@ def install_family_probes(probes, batch):
 
     probes.wrap('lr_expand', lr)
     probes.wrap('lr_expand_tm', lr)          # (x, cum, Tm, pad_row, want_src=...)
-
-
-def lr_expand_family(hip_mod, batch, device, n=50):
-    B, Tx = batch['x'].shape
-    C = 512                                  # 2 * prenet_dims: the width the regulator expands in this model
-    x = torch.randn(B, Tx, C, device=device)
-    cum, _ = hip_mod.lr_scan(batch['dur'].clone())
-    Tm = int(batch['mel_len'].max())
-    ms = lr_back_to_back_ms(hip_mod, (x, cum, Tm), n=n)
-    nbytes = 4.0 * C * (float(batch['x_len'].sum()) + B * Tm)
-    tbs = nbytes / (ms * 1e-3) / 1e12
-    return {'family': 'LengthRegulator expand (ft_lr_expand_kernel), in isolation on the step\'s operand shapes -- the train '
-                      'step itself follows the regulator through a row map and expands nothing',
-            'bound': 'hbm', 'launch_ms': round(ms, 4), 'timing': f'{n} launches back to back between one event pair',
-            'bytes_per_launch': nbytes, 'achieved': round(tbs * 1e3, 1), 'peak': HBM_PEAK_TBS * 1e3, 'unit': 'GB/s',
-            'frac': round(tbs / HBM_PEAK_TBS, 4)}
 
 
 def lr_back_to_back_ms(hip_mod, args, n=50, fn='lr_expand'):
@@ -427,11 +401,6 @@ def main():
             lr_iso = (lr_back_to_back_ms(_hip, fp.lr_args, fn=getattr(fp, 'lr_fn', 'lr_expand'))
                       if getattr(fp, 'lr_args', None) else None)
             fam = family_rooflines(fp.results(), args.family_steps, batch, elapsed / args.steps * 1e3, lr_iso)
-            if not getattr(fp, 'lr_args', None):
-                # The train step no longer EXPANDS anything: the decoder LSTM reads its per-token projection through the
-                # regulator's row map (ops.LRBiLSTMFn).  The expansion kernel itself (generate paths, FastPitch) is still
-                # measured, on the step's own operands: the prenet output's shape and the batch's durations.
-                fam.append(lr_expand_family(_hip, batch, device))
             fam.append(wgrad_family(_hip, device))
         flag = torch.tensor([ok], device=device)
         if world > 1:

@@ -32,7 +32,6 @@ int ft_check_launch(const char* what) {
 int ft_lr_scan_impl(float*, int, int, int*, int*, hipStream_t);
 int ft_lr_expand_impl(const float*, const int*, float*, int*, int, int, int, int, hipStream_t, int = 0, const float* = nullptr);
 int ft_lr_bwd_impl(const float*, const int*, float*, int, int, int, int, hipStream_t, int = 0, float* = nullptr);
-int ft_lr_index_impl(const int*, int*, int, int, int, hipStream_t);
 
 // ft_bn.hip: statistics partials by the stand-alone column pass (C++ linkage), and the partial-buffer size query
 int ft_bn_stat_partials(const float* y, int B, int Tbuf, int C, int group, double* partial, hipStream_t s);
@@ -735,9 +734,6 @@ int ft_lr_expand(const float* x, const int* cum, float* y, int* src_idx, int B, 
 }
 int ft_lr_bwd(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, void* stream) {
   return ft_lr_bwd_impl(dy, cum, dx, B, Tx, Tm, C, (hipStream_t)stream);
-}
-int ft_lr_index(const int* cum, int* src_idx, int B, int Tx, int Tm, void* stream) {
-  return ft_lr_index_impl(cum, src_idx, B, Tx, Tm, (hipStream_t)stream);
 }
 int ft_lr_expand_tm(const float* x, const int* cum, const float* pad_row, float* y, int B, int Tx, int Tm, int C,
                     void* stream) {

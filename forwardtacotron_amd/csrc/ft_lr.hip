@@ -84,24 +84,6 @@ __global__ __launch_bounds__(256) void ft_lr_expand_kernel(const float* __restri
   }
 }
 
-// src_idx[b][t] = token of frame t (largest j with cum[j] <= t, skipping tokens without frames), -1 beyond the item's frames
-__global__ __launch_bounds__(256) void ft_lr_index_kernel(const int* __restrict__ cum, int* __restrict__ src_idx, int Tx,
-                                                          int Tm) {
-  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= Tm) return;
-  const int* c = cum + (long)b * (Tx + 1);
-  int tok = -1;
-  if (t < c[Tx]) {
-    int lo = 0, hi = Tx - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (c[mid] <= t) lo = mid; else hi = mid - 1;
-    }
-    tok = lo;
-  }
-  src_idx[(long)b * Tm + t] = tok;
-}
-
 // one wave per (token row, 256-column chunk): a lane adds the frames' float4 of its 4 columns, in frame order.  dy row of
 // (b, t) = b * dy_bs + t * dy_ts (as in the expand kernel)
 // dtail (optional, [B,C]): rows B*Tx .. B*Tx+B-1 of the grid add up the frames BEYOND item b's tokens (t >= cum[b][Tx]) --
@@ -186,13 +168,6 @@ int ft_lr_expand_impl(const float* x, const int* cum, float* y, int* src_idx, in
   hipLaunchKernelGGL(ft_lr_expand_kernel<FR>, dim3(ft_cdiv(Tm, FR), B), dim3(256), 0, stream, x, cum, y, src_idx,
                      Tx, Tm, C, vec, y_time_major ? 1L : (long)Tm, y_time_major ? (long)B : 1L, pad_row);
   return ft_check_launch("lr_expand");
-}
-
-int ft_lr_index_impl(const int* cum, int* src_idx, int B, int Tx, int Tm, hipStream_t stream) {
-  FT_REQUIRE(B >= 0 && Tx > 0 && Tm >= 0, "lr_index: bad dims");
-  if (B == 0 || Tm == 0) return FT_OK;
-  hipLaunchKernelGGL(ft_lr_index_kernel, dim3(ft_cdiv(Tm, 256), B), dim3(256), 0, stream, cum, src_idx, Tx, Tm);
-  return ft_check_launch("lr_index");
 }
 
 int ft_lr_bwd_impl(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm, int C, hipStream_t stream,

@@ -26,13 +26,6 @@ struct RnnFwdArgs {
   // chunk it has not seen complete, and reads xp past L1.
   const unsigned* gate;
   int gate_cs;
-  // row map (persistent forward only; null = off): the sequence is the LengthRegulator's expansion of xTx token rows and
-  // xp holds ONE projected row per token, batch-major [B, xTx, ND*G*H]; xmap[b*T + t] = token of frame t of item b, or -1
-  // (a frame beyond the item's tokens: its projection is the bias, xpad [ND*G*H]).  The cell threads then read the rows
-  // where they are instead of from a per-frame copy (441 MB at the benchmark shape, 12.8 GB in the long-form batch).
-  const int* xmap;
-  const float* xpad;
-  int xTx;
 };
 
 struct RnnBwdArgs {

@@ -329,23 +329,17 @@ template <int G>
 int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
             float* out, float* cst, float* gates, const long* lens, int B, int T, int H, void* ws,
             size_t ws_bytes, hipStream_t stream, const unsigned* gate = nullptr, int gate_cs = 0,
-            hipEvent_t xp_complete = nullptr, const int* xmap = nullptr, const float* xpad = nullptr, int xTx = 0,
-            int* mapped_done = nullptr) {
+            hipEvent_t xp_complete = nullptr) {
   RnnFwdArgs a;
   a.xp = xp; a.whh[0] = whh_f; a.whh[1] = whh_r; a.bhh[0] = bhh_f; a.bhh[1] = bhh_r;
   a.out = out; a.cst = cst; a.gates = gates; a.lens = lens;
   a.B = B; a.T = T; a.H = H; a.ND = 2; a.Bld = B;
   a.gate = gate; a.gate_cs = gate_cs;
-  a.xmap = xmap; a.xpad = xpad; a.xTx = xTx;
-  if (mapped_done) *mapped_done = 0;
   a.vec = (H % 4 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)whh_f % 16 == 0) && ((uintptr_t)whh_r % 16 == 0);
   const bool fast = a.vec && (H % 16 == 0);
   {
     const int rc = ft_rnn_fwd_persistent(G, a, ws, ws_bytes, stream);      // writes the zeros of finished items itself
-    if (rc != -1) {
-      if (mapped_done) *mapped_done = 1;
-      return rc;
-    }
+    if (rc != -1) return rc;
   }
   // only the single persistent launch reads xp chunk by chunk: every other form waits for all of it
   if (gate) {
@@ -362,8 +356,7 @@ int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float
     auto slice = [&](int bo) {
       RnnFwdArgs c = a;
       const long ldo = (long)a.ND * H;
-      c.xp = a.xp + (a.xmap ? (long)bo * a.xTx : (long)bo) * a.ND * G * H;      // (mapped: batch-major token rows)
-      if (a.xmap) c.xmap = a.xmap + (long)bo * T;
+      c.xp = a.xp + (long)bo * a.ND * G * H;
       c.out = a.out + bo * ldo;
       c.cst = a.cst ? a.cst + bo * ldo : nullptr;
       c.gates = a.gates ? a.gates + (long)bo * a.ND * 4 * H : nullptr;
@@ -377,11 +370,9 @@ int rnn_fwd(const float* xp, const float* whh_f, const float* whh_r, const float
         rc = ft_rnn_fwd_persistent(G, slice(bo), ws, ws_bytes, stream);
         FT_REQUIRE(rc != -1, "rnn_fwd: a later batch slice was refused the persistent form the first one got");
       }
-      if (mapped_done) *mapped_done = 1;
       return rc;
     }
   }
-  if (a.xmap) return FT_OK;        // the per-step kernels need the per-frame copy: the caller expands and calls again
   if (lens) {   // inactive positions must read as zeros
     (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * T * 2 * H, stream);
     if (cst) (void)hipMemsetAsync(cst, 0, sizeof(float) * (size_t)B * T * 2 * H, stream);
@@ -586,15 +577,6 @@ int ft_lstm_fwd(const float* xp, const float* whh_f, const float* whh_r, const f
   hipStream_t s = (hipStream_t)stream;
   return rnn_fwd<4>(xp, whh_f, whh_r, bhh_f, bhh_r, out_raw, cstate, gates, lens, B, T, H, workspace,
                     workspace_bytes, s);
-}
-
-int ft_lstm_fwd_mapped(const float* xp_tok, const int* xmap, const float* xpad, int Tx, const float* whh_f,
-                       const float* whh_r, const float* bhh_f, const float* bhh_r, const long* lens, float* out_raw,
-                       float* cstate, float* gates, int* done, int B, int T, int H, void* workspace, size_t workspace_bytes,
-                       void* stream) {
-  FT_REQUIRE(B > 0 && T >= 0 && H > 0 && Tx > 0 && xp_tok && xmap && xpad && done, "lstm_fwd_mapped: bad arguments");
-  return rnn_fwd<4>(xp_tok, whh_f, whh_r, bhh_f, bhh_r, out_raw, cstate, gates, lens, B, T, H, workspace, workspace_bytes,
-                    (hipStream_t)stream, nullptr, 0, nullptr, xmap, xpad, Tx, done);
 }
 
 int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, const float* gates,

@@ -392,15 +392,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
     }
     __syncthreads();
   }
-  // mapped launches (RnnFwdArgs.xmap): `tok` is the token of frame cn (requested a step ahead of the row itself, so
-  // that the dependent pair index -> row never has to complete within one step)
-  const bool mapped = a.xmap != nullptr;
-  auto xload_tok = [&](int tok, float (&dst)[G]) {
-    const float* xr = tok >= 0 ? a.xp + ((long)cb * a.xTx + tok) * ldx + (long)d * G * H + cun
-                               : a.xpad + (long)d * G * H + cun;
-#pragma unroll
-    for (int g = 0; g < G; ++g) dst[g] = xr[(long)g * H];
-  };
   auto xload = [&](int cn, float (&dst)[G]) {
     const float* xr = a.xp + ((long)cn * a.Bld + cb) * ldx + (long)d * G * H + cun;
     if (gated) {
@@ -412,15 +403,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
       for (int g = 0; g < G; ++g) dst[g] = xr[(long)g * H];
     }
   };
-  int tokn = -1;                         // mapped: the token of the frame of step s + 1 (loaded during step s - 1)
-  if (cthr && 0 < L) {
-    if (mapped) {
-      xload_tok(a.xmap[(long)cb * T + (d == 0 ? 0 : L - 1)], xg);
-      if (1 < L) tokn = a.xmap[(long)cb * T + (d == 0 ? 1 : L - 2)];
-    } else {
-      xload(d == 0 ? 0 : L - 1, xg);
-    }
-  }
+  if (cthr && 0 < L) xload(d == 0 ? 0 : L - 1, xg);
 
   PROF_DECL;
   for (int s = 0; s < T; ++s) {
@@ -442,12 +425,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void ft_rnn_fwd_persist_k
 #pragma unroll
     for (int g = 0; g < G; ++g) xn[g] = 0.f;
     auto request_xn = [&]() {
-      if (mapped) {
-        if (cthr && s + 1 < L) xload_tok(tokn, xn);
-        if (cthr && s + 2 < L) tokn = a.xmap[(long)cb * T + (d == 0 ? s + 2 : L - 3 - s)];
-      } else if (cthr && s + 1 < L) {
-        xload(d == 0 ? s + 1 : L - 2 - s, xn);
-      }
+      if (cthr && s + 1 < L) xload(d == 0 ? s + 1 : L - 2 - s, xn);
     };
     const bool gl = local;              // protocol of THIS step's operands (the mode may change below, at s == 1)
     // granule mode of this step (wave-uniform): XCD-local, bf16-split (file header).  Block c+1 is requested before

@@ -1088,39 +1088,6 @@ def gru_layer_fwd(x, wih_f, wih_r, bih_f, bih_r, whh_f, whh_r, bhh_f, bhh_r, H: 
     return out, gates
 
 
-def lr_index(cum: torch.Tensor, Tm: int) -> torch.Tensor:
-    """[B,Tm] int32: the token of every frame (-1 beyond an item's frames)"""
-    _chk(cum, 'cum', torch.int32)
-    B, Tx1 = cum.shape
-    src = torch.empty(B, Tm, device=cum.device, dtype=torch.int32)
-    _lib.call('ft_lr_index', _p(cum), _p(src), B, Tx1 - 1, Tm, _stream())
-    return src
-
-
-def lstm_fwd_regulated(P: torch.Tensor, cum: torch.Tensor, Tm: int, pad_row: torch.Tensor, whh_f, whh_r, bhh_f, bhh_r,
-                       lens: Optional[torch.Tensor], H: int, save_gates: bool):
-    """lstm_fwd over the LengthRegulator's expansion of the per-token projection P [B,Tx,8H]: the persistent kernel reads
-    the token rows through a row map (ft_lstm_fwd_mapped); where it does not run, the rows are copied out per frame first"""
-    _chk(P, 'P')
-    B, Tx, _ = P.shape
-    dev = P.device
-    raw = torch.empty(Tm, B, 2 * H, device=dev, dtype=P.dtype)
-    cst = torch.empty(Tm, B, 2 * H, device=dev, dtype=P.dtype)
-    gates = torch.empty(Tm, B, 2, 4 * H, device=dev, dtype=P.dtype) if save_gates else None
-    ws, nb = _rnn_workspace(4, B, H, dev)
-    if os.environ.get('FT_LR_MAPPED', '1') != '0' and ws is not None:
-        tok = lr_index(cum, Tm)
-        done = ctypes.c_int(0)
-        _lib.call('ft_lstm_fwd_mapped', _p(P), _p(tok), _p(pad_row), Tx, _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r),
-                  _p(lens), _p(raw), _p(cst), _p(gates), ctypes.byref(done), B, Tm, H, _p(ws), nb, _stream())
-        if done.value:
-            return raw, cst, gates
-    xp = lr_expand_tm(P, cum, Tm, pad_row)
-    _lib.call('ft_lstm_fwd', _p(xp), _p(whh_f), _p(whh_r), _p(bhh_f), _p(bhh_r), _p(lens), _p(raw), _p(cst),
-              _p(gates), B, Tm, H, _p(ws), nb, _stream())
-    return raw, cst, gates
-
-
 def lstm_bwd(dout, raw, cst, gates, whhT_f, whhT_r, lens: Optional[torch.Tensor], H: int):
     _chk(dout, 'dout')
     T, B, _ = raw.shape

@@ -682,9 +682,8 @@ class LRBiLSTMFn(Function):
     The LSTM's input projection x W_ih^T + b_ih is a row-wise linear map and the regulator only REPEATS rows, so the two
     commute: the projection is formed once per TOKEN (B x Tx = 4,096 rows at the benchmark shape instead of 26,912
     frames -- 6.6x fewer flops, by the same kernel in the same k order, so every row has exactly the bits the frame-level
-    GEMM gives it) and the persistent recurrence reads the token rows through the regulator's row map (ft_lr_index,
-    ft_lstm_fwd_mapped; frames beyond an item's length read the bias: the projection of the regulator's zero rows) --
-    where it does not run, ft_lr_expand_tm writes the rows out per frame in the recurrence's time-major layout first.  Backward: the
+    GEMM gives it) and ft_lr_expand_tm writes it out per frame, straight into the recurrence's time-major layout
+    (frames beyond an item's length hold the bias: the projection of the regulator's zero rows).  Backward: the
     d(pre-activations) of each token's frames are added up first (ft_lr_bwd_tm -- what the regulator's backward does to
     any gradient), and W_ih's input / weight / bias gradients are token-level GEMMs and sums.  The forward is
     bit-identical to LengthRegulateFn + BiLSTMFn; the backward adds the same numbers in another order (frames of a token
@@ -700,8 +699,8 @@ class LRBiLSTMFn(Function):
         Tm = lr_frames(total, lens)
         # [B,Tx,8H], one row per token, by the kernel the frame-level launch (B * Tm rows) would take
         P = H.linear_multi_fwd(x, [w_ih_f, w_ih_r], [b_ih_f, b_ih_r], as_rows=max(1, x.shape[0] * Tm))
-        raw, cst, gates = H.lstm_fwd_regulated(P, cum, Tm, torch.cat([b_ih_f.detach(), b_ih_r.detach()]), w_hh_f, w_hh_r,
-                                               b_hh_f, b_hh_r, lens, Hh, save_gates=train)
+        xp = H.lr_expand_tm(P, cum, Tm, torch.cat([b_ih_f.detach(), b_ih_r.detach()]))
+        raw, cst, gates = H.lstm_fwd(xp, w_hh_f, w_hh_r, b_hh_f, b_hh_r, lens, Hh, save_gates=train)
         if train:
             ctx.save_for_backward(x, cum, raw, cst, gates, lens, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
                                   b_ih_r, b_hh_r)

@@ -216,9 +216,6 @@ int ft_lr_bwd(const float* dy, const int* cum, float* dx, int B, int Tx, int Tm,
  * token's frames, and the input / weight gradients of W_ih are token-level GEMMs (forward_tacotron.py:145-152). */
 int ft_lr_expand_tm(const float* x, const int* cum, const float* pad_row, float* y, int B, int Tx, int Tm, int C,
                     void* stream);
-/* src_idx[b][t] (int32 [B,Tm]) = token of frame t of item b, -1 beyond the item's frames: the regulator's expansion as a
- * row map (what ft_lr_expand also returns as a by-product) */
-int ft_lr_index(const int* cum, int* src_idx, int B, int Tx, int Tm, void* stream);
 /* dtail (optional, [B,C]): per item, the sum of the frames beyond its last token (t >= total[b]) -- they reach no token,
  * but the bias gradients are column sums over ALL frames (an unpacked LSTM runs over those frames too) */
 int ft_lr_bwd_tm(const float* dy, const int* cum, float* dx, float* dtail, int B, int Tx, int Tm, int C, void* stream);
@@ -429,14 +426,6 @@ int ft_gru_bwd(const float* dout, const float* out, const float* gates, const fl
 int ft_lstm_fwd(const float* xp, const float* whh_f, const float* whh_r, const float* bhh_f, const float* bhh_r,
                 const long* lens, float* out_raw, float* cstate, float* gates, int B, int T, int H,
                 void* workspace, size_t workspace_bytes, void* stream);
-/* ft_lstm_fwd of a REGULATED layer without the per-frame copy of the projection: xp_tok [B,Tx,8H] holds one projected row
- * per token, xmap [B,T] (ft_lr_index) says which row a frame reads, xpad [8H] is the row of frames beyond an item's tokens
- * (the bias).  Only the persistent form can follow a row map: *done (host int) = 1 if it ran, 0 if nothing was launched --
- * the caller then expands (ft_lr_expand_tm) and calls ft_lstm_fwd.  Same values read, same results. */
-int ft_lstm_fwd_mapped(const float* xp_tok, const int* xmap, const float* xpad, int Tx, const float* whh_f,
-                       const float* whh_r, const float* bhh_f, const float* bhh_r, const long* lens, float* out_raw,
-                       float* cstate, float* gates, int* done, int B, int T, int H, void* workspace, size_t workspace_bytes,
-                       void* stream);
 int ft_lstm_bwd(const float* dout, const float* out_raw, const float* cstate, const float* gates,
                 const float* whhT_f, const float* whhT_r, const long* lens, float* dgates, float* carry, int B, int T,
                 int H, void* workspace, size_t workspace_bytes, void* stream);
